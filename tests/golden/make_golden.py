@@ -1,0 +1,200 @@
+"""Golden-vector generator: runs the REAL reference (/root/reference, imported with the SURVEY.md
+Appendix C recipe) on synthetic weights/inputs from oracle/synth.py and stores inputs-by-seed +
+expected outputs as small fixtures next to this file.  Runs only in the build container; the GPU box
+never has /root/reference and never runs this.  Usage: python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import _ref_import  # noqa: E402
+
+tv = _ref_import.setup()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import synth  # noqa: E402
+from oracle.nms import tv_nms  # noqa: E402
+
+# stand-in for the absent third-party torchvision.ops.nms (PARITY UNPINNED there, see oracle/nms.py)
+tv.ops.nms = lambda b, s, t: torch.as_tensor(tv_nms(b.numpy(), s.numpy(), t), dtype=torch.long)
+
+from ultralytics.nn.tasks import DetectionModel  # noqa: E402
+from ultralytics.nn.modules import block as rb, conv as rc  # noqa: E402
+from ultralytics.utils import ops as rops, tal as rtal  # noqa: E402
+from ultralytics.utils.torch_utils import fuse_conv_and_bn  # noqa: E402
+
+torch.set_grad_enabled(False)
+YAMLS = ["yolo11", "yolo11-test", "yolo11-tune", "yolo11-lineattention", "yolo11-DSC3K2_Wavelet", "yolo11-GF2Detect"]
+
+
+def build(name, nc=80):
+    m = DetectionModel(name, ch=3, nc=nc, verbose=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes))
+    return m, shapes
+
+
+def structure():
+    out = {}
+    for y in YAMLS:
+        for sc in (["n", "s", "l"] if y in ("yolo11", "yolo11-test") else ["n"]):
+            name = y.replace("yolo11", "yolo11" + sc) + ".yaml"
+            m = DetectionModel(name, ch=3, nc=80, verbose=False)
+            e = dict(params=sum(p.numel() for p in m.parameters()), save=list(m.save),
+                     stride=[float(s) for s in m.stride],
+                     layers=[dict(i=l.i, f=l.f, type=l.type, np=int(l.np)) for l in m.model],
+                     nkeys=len(m.state_dict()), nelem=sum(v.numel() for v in m.state_dict().values()))
+            if sc == "n":
+                e["state_shapes"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+            out[name] = e
+            print(name, e["params"])
+    # nc=10 (GC10-DET) changes the cls tower width c3 (head.py:59)
+    m = DetectionModel("yolo11n-test.yaml", ch=3, nc=10, verbose=False)
+    out["yolo11n-test.yaml@nc10"] = dict(params=sum(p.numel() for p in m.parameters()),
+                                         state_shapes={k: list(v.shape) for k, v in m.state_dict().items() if k.startswith("model.23.cv3.0")})
+    json.dump(out, open(os.path.join(HERE, "structure.json"), "w"), indent=0)
+
+
+HOOKS = {  # inner modules whose outputs pin the per-op restatements
+    "yolo11n-test.yaml": ["model.2.cv1", "model.2.wave.f_ll", "model.2.wave", "model.2.m.0.cv1", "model.2.m.0", "model.6.m.0",
+                          "model.10.m.0.attn", "model.10.m.0", "model.23.cv2.0", "model.23.cv3.0.0.0", "model.23.cv3.0", "model.23.reg_conf.0"],
+    "yolo11n.yaml": ["model.2.m.0", "model.6.m.0", "model.10.m.0.attn", "model.10.m.0"],
+}
+
+
+def model_small(name, tag, b=2, h=64, w=64, layers=True):
+    m, _ = build(name)
+    m.fuse(verbose=False)
+    d = {}
+    mods = dict(m.named_modules())
+    hs = []
+    for i, l in enumerate(m.model if layers else []):
+        hs.append(l.register_forward_hook(lambda mod, inp, out, i=i: d.__setitem__(f"layer{i}", out.clone()) if torch.is_tensor(out) else None))
+    for k in HOOKS.get(name, []) if layers else []:
+        hs.append(mods[k].register_forward_hook(lambda mod, inp, out, k=k: d.__setitem__(k, out.clone())))
+    x = synth.synth_images(b, h, w)
+    y, raw = m(x)
+    d["y"] = y
+    for i, r in enumerate(raw):
+        d[f"raw{i}"] = r
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **{k: v.numpy() for k, v in d.items()})
+    print(tag, len(d), y.shape)
+
+
+def model_640(name, tag, h=640, w=640, step=7):
+    m, _ = build(name)
+    m.fuse(verbose=False)
+    y, raw = m(synth.synth_images(1, h, w))
+    d = dict(y_sub=y[:, :, ::step].numpy(), step=np.int64(step), row_sum=y.double().sum(-1).numpy(),
+             row_abs=y.double().abs().sum(-1).numpy())
+    # the full predict-time post-process on the same output (conf .25, iou .7: cfg/default.yaml:51-65)
+    det = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300)
+    d["det0"] = det[0].numpy()
+    np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **d)
+    print(tag, y.shape, det[0].shape)
+
+
+def ops_small():
+    d = {}
+    # Haar DWT known answer + random (block.py:3582-3642)
+    dwt = rb._PywtDWT2D("haar")
+    for k, t in zip(("LL", "LH", "HL", "HH"), dwt(torch.tensor([[[[1., 2.], [3., 4.]]]]))):
+        d["dwt_quad_" + k] = t
+    x = synth.synth_images(2, 6, 10, c=4) * 2 - 1
+    for k, t in zip(("LL", "LH", "HL", "HH"), dwt(x)):
+        d["dwt_rand_" + k] = t
+    xo = synth.synth_images(1, 5, 7, c=2)
+    for k, t in zip(("LL", "LH", "HL", "HH"), dwt(xo)):
+        d["dwt_odd_" + k] = t
+
+    def filled(mod, prefix):
+        mod.eval()
+        for mm in mod.modules():
+            if isinstance(mm, torch.nn.BatchNorm2d):
+                mm.eps = 1e-3  # initialize_weights, torch_utils.py:416
+        mod.load_state_dict(synth.synth_state_dict({prefix + "." + k: tuple(v.shape) for k, v in mod.state_dict().items()}) and
+                            {k: synth.synth_tensor(prefix + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()})
+        return mod
+
+    # enhancer on even and odd maps (block.py:3645-3710)
+    enh = filled(rb._WaveletEnhancer(16), "enh")
+    d["enh_even"] = enh(synth.synth_images(2, 10, 14, c=16) - 0.5)
+    d["enh_odd"] = enh(synth.synth_images(1, 9, 13, c=16) - 0.5)
+    for k in (3, 5, 7):  # DSConv (conv.py:87-104)
+        ds = filled(rc.DSConv(16, 24, k), f"ds{k}")
+        d[f"dsconv{k}"] = ds(synth.synth_images(2, 9, 11, c=16) - 0.5)
+    sp = filled(rb.SPPF(32, 48, 5), "sppf")
+    d["sppf"] = sp(synth.synth_images(1, 7, 9, c=32) - 0.5)
+    la = filled(rb.PSABlock_LinearAttention(128, num_heads=2), "psa_la")
+    d["psa_la"] = la(synth.synth_images(2, 4, 4, c=128) - 0.5)
+    at = filled(rb.PSABlock(128, num_heads=2), "psa")
+    d["psa"] = at(synth.synth_images(2, 4, 4, c=128) - 0.5)
+    cv = filled(rc.Conv(16, 24, 3, 2), "conv_s2")
+    d["conv_s2_unfused"] = cv(synth.synth_images(2, 9, 11, c=16) - 0.5)
+    fc = fuse_conv_and_bn(cv.conv, cv.bn)
+    d["conv_s2_fused_w"], d["conv_s2_fused_b"] = fc.weight, fc.bias
+    # anchors / dist2bbox (tal.py:333-357)
+    feats = [torch.zeros(1, 8, 4, 6), torch.zeros(1, 8, 2, 3), torch.zeros(1, 8, 1, 2)]
+    a, s = rtal.make_anchors(feats, torch.tensor([8., 16., 32.]), 0.5)
+    d["anchors"], d["anchor_strides"] = a, s
+    dist = synth.synth_images(1, 4, a.shape[0], c=1)[0] * 5
+    d["dist2bbox"] = rtal.dist2bbox(dist, a.t().unsqueeze(0), xywh=True, dim=1)
+    d["make_divisible"] = torch.tensor([rops.make_divisible(v, 8) for v in (16.0, 17.0, 64 * 0.25, 1024 * 0.25, 100 * 1.5)])
+    np.savez_compressed(os.path.join(HERE, "ops_small.npz"), **{k: v.numpy() for k, v in d.items()})
+    print("ops_small", len(d))
+
+
+def nms_cases():
+    d, meta = {}, {}
+
+    def run(tag, pred, **kw):
+        out = rops.non_max_suppression(pred.clone(), **kw)
+        meta[tag] = dict(kw=kw, n=[int(o.shape[0]) for o in out])
+        for i, o in enumerate(out):
+            d[f"{tag}_{i}"] = o.numpy()
+
+    sparse = synth.synth_pred(2, 80, 8400, seed=2)
+    run("sparse", sparse, conf_thres=0.25, iou_thres=0.7)
+    run("sparse_iou45_det20", sparse, conf_thres=0.25, iou_thres=0.45, max_det=20)
+    run("sparse_agnostic", sparse, conf_thres=0.25, iou_thres=0.7, agnostic=True)
+    run("sparse_classes", sparse, conf_thres=0.25, iou_thres=0.7, classes=[0, 3, 17])
+    dense = synth.synth_pred(1, 80, 8400, seed=3, dense=True)
+    run("dense", dense, conf_thres=0.25, iou_thres=0.7)
+    run("val_multilabel", synth.synth_pred(1, 80, 2100, seed=4, dense=True), conf_thres=0.001, iou_thres=0.7, multi_label=True, max_det=300)
+    small = synth.synth_pred(1, 10, 336, seed=5, imgsz=128, dense=True)
+    run("nc10", small, conf_thres=0.25, iou_thres=0.7)
+    run("none_pass", synth.synth_pred(2, 80, 336, seed=6) * torch.tensor(1e-3), conf_thres=0.25, iou_thres=0.7)
+    # hand-made: score ties, identical boxes, class-offset separation, touching boxes, zero-area box
+    hand = torch.zeros(1, 4 + 3, 12)
+    bx = [(50, 50, 40, 40), (52, 50, 40, 40), (50, 52, 40, 40), (50, 50, 40, 40), (150, 50, 40, 40), (190, 50, 40, 40),
+          (50, 50, 40, 40), (300, 300, 0, 0), (300, 300, 10, 10), (302, 300, 10, 10), (52, 52, 40, 40), (48, 50, 40, 40)]
+    sc = [0.9, 0.9, 0.9, 0.8, 0.7, 0.7, 0.6, 0.5, 0.5, 0.5, 0.26, 0.2]
+    cl = [0, 0, 1, 0, 2, 2, 1, 0, 0, 0, 0, 0]
+    for i, (b, s, c) in enumerate(zip(bx, sc, cl)):
+        hand[0, :4, i] = torch.tensor(b, dtype=torch.float32)
+        hand[0, 4 + c, i] = s
+    d["hand_pred"] = hand.numpy()
+    run("hand", hand, conf_thres=0.25, iou_thres=0.45)
+    run("hand_agn", hand, conf_thres=0.25, iou_thres=0.45, agnostic=True)
+    np.savez_compressed(os.path.join(HERE, "nms_cases.npz"), **d)
+    json.dump(meta, open(os.path.join(HERE, "nms_cases.json"), "w"), indent=0)
+    print("nms", meta)
+
+
+if __name__ == "__main__":
+    structure()
+    ops_small()
+    nms_cases()
+    model_small("yolo11n-test.yaml", "edgeline_n_64")
+    model_small("yolo11n.yaml", "yolo11n_64")
+    for abl in ("GF2Detect", "lineattention", "DSC3K2_Wavelet", "tune"):
+        model_small(f"yolo11n-{abl}.yaml", f"{abl.lower()}_n_64", b=1, layers=False)
+    model_small("yolo11n-test.yaml", "edgeline_n_96x160", b=1, h=96, w=160, layers=False)
+    model_640("yolo11n-test.yaml", "edgeline_n_640")
+    model_640("yolo11n.yaml", "yolo11n_640")

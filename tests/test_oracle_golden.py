@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth
+from oracle import model as om
+from oracle import nms as onms
+
+TOL = dict(rtol=1e-4, atol=2e-5)
+
+
+def _load(golden_dir, name):
+    return {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+@pytest.fixture(scope="module")
+def structure(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "structure.json")))
+
+
+def _oracle(cfg_dir, structure, name):
+    shapes = {k: tuple(v) for k, v in structure[name]["state_shapes"].items()}
+    return om.OracleModel(os.path.join(cfg_dir, name), synth.synth_state_dict(shapes))
+
+
+@pytest.mark.parametrize("name", ["yolo11n.yaml", "yolo11s.yaml", "yolo11l.yaml", "yolo11n-test.yaml", "yolo11s-test.yaml",
+                                  "yolo11l-test.yaml", "yolo11n-tune.yaml", "yolo11n-lineattention.yaml",
+                                  "yolo11n-DSC3K2_Wavelet.yaml", "yolo11n-GF2Detect.yaml"])
+def test_graph_matches_reference(cfg_dir, structure, name):
+    g = structure[name]
+    layers, save, legacy = om.parse_graph(om.load_yaml(os.path.join(cfg_dir, name)))
+    assert save == g["save"]
+    assert [l["f"] for l in layers] == [l["f"] for l in g["layers"]]
+    assert [l["type"] for l in layers] == [l["type"].rsplit(".", 1)[-1].replace("Upsample", "nn.Upsample") for l in g["layers"]]
+
+
+@pytest.mark.parametrize("name,tag,per_layer", [("yolo11n-test.yaml", "edgeline_n_64", True), ("yolo11n.yaml", "yolo11n_64", True),
+                                                ("yolo11n-GF2Detect.yaml", "gf2detect_n_64", False),
+                                                ("yolo11n-lineattention.yaml", "lineattention_n_64", False),
+                                                ("yolo11n-DSC3K2_Wavelet.yaml", "dsc3k2_wavelet_n_64", False),
+                                                ("yolo11n-tune.yaml", "tune_n_64", False)])
+def test_model_small(cfg_dir, golden_dir, structure, name, tag, per_layer):
+    g = _load(golden_dir, tag)
+    o = _oracle(cfg_dir, structure, name)
+    b = g["y"].shape[0]
+    outs = []
+    y, raw = o.forward(synth.synth_images(b, 64, 64), outs)
+    torch.testing.assert_close(y, g["y"], rtol=1e-4, atol=2e-4)  # boxes are O(100) px
+    for i, r in enumerate(raw):
+        torch.testing.assert_close(r, g[f"raw{i}"], **TOL)
+    if per_layer:
+        for i, t in enumerate(outs[:-1]):
+            torch.testing.assert_close(t, g[f"layer{i}"], **TOL)
+
+
+def test_model_nonsquare(cfg_dir, golden_dir, structure):
+    g = _load(golden_dir, "edgeline_n_96x160")
+    y, raw = _oracle(cfg_dir, structure, "yolo11n-test.yaml")(synth.synth_images(1, 96, 160))
+    torch.testing.assert_close(y, g["y"], rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,tag", [("yolo11n-test.yaml", "edgeline_n_640"), ("yolo11n.yaml", "yolo11n_640")])
+def test_model_640_and_postprocess(cfg_dir, golden_dir, structure, name, tag):
+    g = _load(golden_dir, tag)
+    y, _ = _oracle(cfg_dir, structure, name)(synth.synth_images(1, 640, 640))
+    step = int(g["step"])
+    torch.testing.assert_close(y[:, :, ::step], g["y_sub"], rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(y.double().sum(-1), g["row_sum"], rtol=1e-5, atol=1e-1)
+    det = onms.non_max_suppression(y.numpy(), 0.25, 0.7)[0]
+    # same kept set / order unless a decision sits within fp32 noise of a threshold: compare rows with tolerance
+    assert det.shape == tuple(g["det0"].shape)
+    np.testing.assert_allclose(det, g["det0"].numpy(), rtol=1e-4, atol=2e-3)
+
+
+def test_inner_modules(cfg_dir, golden_dir, structure):
+    """Per-op pins through forward-hook captures inside the reference EdgeLine model."""
+    g = _load(golden_dir, "edgeline_n_64")
+    o = _oracle(cfg_dir, structure, "yolo11n-test.yaml")
+    sd = o.sd
+    x1 = g["layer1"]
+    cv1 = om.conv(sd, "model.2.cv1", x1)
+    torch.testing.assert_close(cv1, g["model.2.cv1"], **TOL)
+    b = cv1.chunk(2, 1)[1]
+    LL = om.haar_dwt(b)[0]
+    torch.testing.assert_close(om.conv(sd, "model.2.wave.f_ll", LL), g["model.2.wave.f_ll"], **TOL)
+    bw = om.wavelet_enhancer(sd, "model.2.wave", b)
+    torch.testing.assert_close(bw, g["model.2.wave"], **TOL)
+    torch.testing.assert_close(om.dsconv(sd, "model.2.m.0.cv1", bw, 3), g["model.2.m.0.cv1"], **TOL)
+    torch.testing.assert_close(om.dsbottleneck(sd, "model.2.m.0", bw, 3, 7), g["model.2.m.0"], **TOL)
+    x16 = g["layer16"]
+    t = om.conv(sd, "model.23.cv2.0.1", om.conv(sd, "model.23.cv2.0.0", x16, 3), 3)
+    box = torch.nn.functional.conv2d(t, sd["model.23.cv2.0.2.weight"], sd["model.23.cv2.0.2.bias"])
+    torch.testing.assert_close(box, g["model.23.cv2.0"], **TOL)
+    torch.testing.assert_close(om.dwconv(sd, "model.23.cv3.0.0.0", x16, 3), g["model.23.cv3.0.0.0"], **TOL)
+    torch.testing.assert_close(box, g["raw0"][:, :64], **TOL)
+
+
+def test_ops_small(golden_dir):
+    g = _load(golden_dir, "ops_small")
+    LL, LH, HL, HH = om.haar_dwt(torch.tensor([[[[1., 2.], [3., 4.]]]]))
+    for k, t in zip(("LL", "LH", "HL", "HH"), (LL, LH, HL, HH)):
+        torch.testing.assert_close(t, g["dwt_quad_" + k], rtol=0, atol=1e-6)
+    assert [round(float(t)) for t in (LL, LH, HL, HH)] == [5, -1, -2, 0]
+    for tag, x in (("rand", synth.synth_images(2, 6, 10, c=4) * 2 - 1), ("odd", synth.synth_images(1, 5, 7, c=2))):
+        for k, t in zip(("LL", "LH", "HL", "HH"), om.haar_dwt(x)):
+            torch.testing.assert_close(t, g[f"dwt_{tag}_{k}"], **TOL)
+
+    def sd_for(prefix, shapes):
+        return {prefix + "." + k: synth.synth_tensor(prefix + "." + k, s) for k, s in shapes.items()}
+
+    def conv_shapes(c1, c2, k, g_=1):
+        return {"conv.weight": (c2, c1 // g_, k, k), "bn.weight": (c2,), "bn.bias": (c2,), "bn.running_mean": (c2,), "bn.running_var": (c2,)}
+
+    def pre(p, d):
+        return {p + "." + k: v for k, v in d.items()}
+
+    enh = {**pre("f_ll", conv_shapes(16, 8, 1)), **pre("f_h", conv_shapes(16, 8, 3)), **pre("fuse", conv_shapes(48, 16, 1)),
+           "alpha": (4,), "gamma": ()}
+    sd = sd_for("enh", enh)
+    torch.testing.assert_close(om.wavelet_enhancer(sd, "enh", synth.synth_images(2, 10, 14, c=16) - 0.5), g["enh_even"], **TOL)
+    torch.testing.assert_close(om.wavelet_enhancer(sd, "enh", synth.synth_images(1, 9, 13, c=16) - 0.5), g["enh_odd"], **TOL)
+    for k in (3, 5, 7):
+        sd = sd_for(f"ds{k}", {"dw.weight": (16, 1, k, k), "pw.weight": (24, 16, 1, 1), "bn.weight": (24,), "bn.bias": (24,),
+                               "bn.running_mean": (24,), "bn.running_var": (24,)})
+        torch.testing.assert_close(om.dsconv(sd, f"ds{k}", synth.synth_images(2, 9, 11, c=16) - 0.5, k), g[f"dsconv{k}"], **TOL)
+    sd = sd_for("sppf", {**pre("cv1", conv_shapes(32, 16, 1)), **pre("cv2", conv_shapes(64, 48, 1))})
+    torch.testing.assert_close(om.sppf(sd, "sppf", synth.synth_images(1, 7, 9, c=32) - 0.5), g["sppf"], **TOL)
+    ffn = {**pre("ffn.0", conv_shapes(128, 256, 1)), **pre("ffn.1", conv_shapes(256, 128, 1))}
+    sd = sd_for("psa_la", {"attn.qkv.weight": (384, 128, 1, 1), "attn.qkv.bias": (384,), "attn.proj.weight": (128, 128, 1, 1), **ffn})
+    x = synth.synth_images(2, 4, 4, c=128) - 0.5
+    b = x + om.linear_attention(sd, "psa_la.attn", x, 2)
+    b = b + om.conv(sd, "psa_la.ffn.1", om.conv(sd, "psa_la.ffn.0", b), act=False)
+    torch.testing.assert_close(b, g["psa_la"], **TOL)
+    sd = sd_for("psa", {**pre("attn.qkv", conv_shapes(128, 256, 1)), **pre("attn.proj", conv_shapes(128, 128, 1)),
+                        **pre("attn.pe", conv_shapes(128, 128, 3, 128)), **ffn})
+    b = x + om.attention(sd, "psa.attn", x, 2)
+    b = b + om.conv(sd, "psa.ffn.1", om.conv(sd, "psa.ffn.0", b), act=False)
+    torch.testing.assert_close(b, g["psa"], **TOL)
+    sd = sd_for("conv_s2", conv_shapes(16, 24, 3))
+    w, bias = om._fold(sd, "conv_s2")
+    torch.testing.assert_close(w, g["conv_s2_fused_w"], **TOL)
+    torch.testing.assert_close(bias, g["conv_s2_fused_b"], **TOL)
+    torch.testing.assert_close(om.conv(sd, "conv_s2", synth.synth_images(2, 9, 11, c=16) - 0.5, 3, 2), g["conv_s2_unfused"], **TOL)
+    a, s = om.make_anchors([(4, 6), (2, 3), (1, 2)], [8., 16., 32.])
+    torch.testing.assert_close(a, g["anchors"], rtol=0, atol=0)
+    torch.testing.assert_close(s, g["anchor_strides"], rtol=0, atol=0)
+    assert [om.make_divisible(v, 8) for v in (16.0, 17.0, 16.0, 256.0, 150.0)] == [int(v) for v in g["make_divisible"]]
+
+
+def test_nms_cases(golden_dir):
+    """oracle.nms vs the reference's own non_max_suppression (ops.py:167-316) run with the tv_nms stand-in:
+    pins everything AROUND torchvision.ops.nms bit-exactly (that inner boundary itself stays unpinned)."""
+    g = np.load(os.path.join(golden_dir, "nms_cases.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "nms_cases.json")))
+    preds = {
+        "sparse": synth.synth_pred(2, 80, 8400, seed=2), "dense": synth.synth_pred(1, 80, 8400, seed=3, dense=True),
+        "val_multilabel": synth.synth_pred(1, 80, 2100, seed=4, dense=True),
+        "nc10": synth.synth_pred(1, 10, 336, seed=5, imgsz=128, dense=True),
+        "none_pass": synth.synth_pred(2, 80, 336, seed=6) * torch.tensor(1e-3), "hand": torch.tensor(g["hand_pred"]),
+    }
+    for tag, m in meta.items():
+        base = "sparse" if tag.startswith("sparse") else "hand" if tag.startswith("hand") else tag
+        out = onms.non_max_suppression(preds[base].numpy(), **m["kw"])
+        assert [o.shape[0] for o in out] == m["n"], tag
+        for i, o in enumerate(out):
+            np.testing.assert_array_equal(o, g[f"{tag}_{i}"], err_msg=tag)  # bit-exact
