@@ -1,0 +1,17 @@
+// Error reporting and version of libedgeyolo_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/edgeyolo_hip.h"
+
+static thread_local char g_err[512] = "";
+
+int ey_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* ey_last_error(void) { return g_err; }
+extern "C" int ey_version(void) { return 1; }

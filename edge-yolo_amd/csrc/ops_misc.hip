@@ -1,0 +1,397 @@
+// HBM-bound NHWC operators of the EdgeLine-YOLO forward path: stem conv, depthwise conv, Haar DWT, SPPF pooling,
+// slice copies / layout transposes, and the generic scalar direct convolution (correctness path for odd shapes).
+#include "common.h"
+
+// ============================================================================ generic direct conv (scalar)
+template <typename T>
+__global__ void conv_direct_kernel(ey_conv_direct_desc d) {
+  const long total = (long)d.B * d.Ho * d.Wo * d.Cout;
+  const int cpg_in = d.Cin / d.groups, cpg_out = d.Cout / d.groups;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % d.Cout);
+    long m = idx / d.Cout;
+    const int ox = (int)(m % d.Wo);
+    m /= d.Wo;
+    const int oy = (int)(m % d.Ho);
+    const int b = (int)(m / d.Ho);
+    const int grp = co / cpg_out;
+    float acc = d.bias ? d.bias[co] : 0.f;
+    for (int ky = 0; ky < d.k; ++ky) {
+      const int iy = oy * d.stride - d.pad + ky;
+      if (iy < 0 || iy >= d.H) continue;
+      for (int kx = 0; kx < d.k; ++kx) {
+        const int ix = ox * d.stride - d.pad + kx;
+        if (ix < 0 || ix >= d.W) continue;
+        const T* xp = (const T*)d.x + (((long)b * d.H + iy) * d.W + ix) * d.x_cstride + grp * cpg_in;
+        const float* wp = d.w_oihw + ((long)co * cpg_in * d.k + ky) * d.k + kx;
+        for (int c = 0; c < cpg_in; ++c) acc += to_f(xp[c]) * wp[(long)c * d.k * d.k];
+      }
+    }
+    ((T*)d.y)[(((long)b * d.Ho + oy) * d.Wo + ox) * d.y_cstride + co] = from_f<T>(ey_act(acc, d.act));
+  }
+}
+
+extern "C" int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream) {
+  EY_CHECK(d && d->x && d->w_oihw && d->y, "conv_direct: null pointer");
+  EY_CHECK(d->dtype == EY_F16 || d->dtype == EY_F32, "conv_direct: bad dtype");
+  EY_CHECK(d->groups > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0, "conv_direct: groups=%d Cin=%d Cout=%d", d->groups, d->Cin, d->Cout);
+  EY_CHECK(d->k > 0 && d->stride > 0 && d->Ho == (d->H + 2 * d->pad - d->k) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->k) / d->stride + 1,
+           "conv_direct: inconsistent extents");
+  EY_CHECK(d->x_cstride >= d->Cin && d->y_cstride >= d->Cout, "conv_direct: cstride");
+  const long total = (long)d->B * d->Ho * d->Wo * d->Cout;
+  const int blocks = (int)((total + 255) / 256 < 65535 * 16 ? (total + 255) / 256 : 65535 * 16);
+  if (d->dtype == EY_F16) hipLaunchKernelGGL(conv_direct_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(conv_direct_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *d);
+  EY_LAUNCH_CHECK("ey_conv2d_direct");
+  return EY_OK;
+}
+
+// ============================================================================ stem: NCHW image -> NHWC, 3x3 s2
+// One thread = one output pixel x 16 output channels.  Weights are wave-uniform (scalar loads); the 27 input
+// taps are read once per thread from the planar image (adjacent threads read adjacent columns).
+template <typename TI, typename TO, int CIN>
+__global__ __launch_bounds__(256) void stem_kernel(int B, int H, int W, int Ho, int Wo, int Cout, int act, const TI* __restrict__ x,
+                                                   const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ y, int yCs) {
+  const long M = (long)B * Ho * Wo;
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int co0 = blockIdx.y * 16;
+  const int ox = (int)(m % Wo);
+  const long t = m / Wo;
+  const int oy = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  float in[CIN * 9];
+#pragma unroll
+  for (int c = 0; c < CIN; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        in[(c * 3 + ky) * 3 + kx] = ok ? to_f(x[(((long)b * CIN + c) * H + iy) * W + ix]) : 0.f;
+      }
+  float acc[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    float a = bias ? bias[co0 + o] : 0.f;
+    const float* wo = w + (long)(co0 + o) * CIN * 9;
+#pragma unroll
+    for (int i = 0; i < CIN * 9; ++i) a += in[i] * wo[i];
+    acc[o] = ey_act(a, act);
+  }
+  TO* yp = y + m * yCs + co0;
+  Vec8<TO> v0, v1;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) { v0.set(o, acc[o]); v1.set(o, acc[8 + o]); }
+  v0.store(yp);
+  v1.store(yp + 8);
+}
+
+template <typename TI, typename TO>
+static int stem_launch(int B, int Cin, int H, int W, int Cout, int act, const void* x, const float* w, const float* bias, void* y, int yCs, hipStream_t st) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long M = (long)B * Ho * Wo;
+  dim3 grid((unsigned)((M + 255) / 256), Cout / 16);
+#define STEM(CI) hipLaunchKernelGGL((stem_kernel<TI, TO, CI>), grid, dim3(256), 0, st, B, H, W, Ho, Wo, Cout, act, (const TI*)x, w, bias, (TO*)y, yCs)
+  switch (Cin) {
+    case 1: STEM(1); break;
+    case 2: STEM(2); break;
+    case 3: STEM(3); break;
+    default: STEM(4); break;
+  }
+#undef STEM
+  EY_LAUNCH_CHECK("ey_stem_conv");
+  return EY_OK;
+}
+
+extern "C" int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cout, int act, const void* x, const float* w,
+                            const float* bias, void* y, int y_cstride, ey_stream_t stream) {
+  EY_CHECK(x && w && y, "stem: null pointer");
+  EY_CHECK(Cin >= 1 && Cin <= 4 && Cout % 16 == 0 && Cout > 0, "stem: Cin=%d (1..4) Cout=%d (multiple of 16)", Cin, Cout);
+  EY_CHECK(B > 0 && H > 0 && W > 0, "stem: bad extent");
+  const int es = y_dtype == EY_F16 ? 2 : 4;
+  EY_CHECK(y_cstride >= Cout && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16), "stem: output view not 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == EY_F16 && y_dtype == EY_F16) return stem_launch<f16, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
+  if (x_dtype == EY_F32 && y_dtype == EY_F16) return stem_launch<float, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
+  if (x_dtype == EY_F16 && y_dtype == EY_F32) return stem_launch<f16, float>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
+  if (x_dtype == EY_F32 && y_dtype == EY_F32) return stem_launch<float, float>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
+  return ey_set_error(EY_EINVAL, "stem: bad dtype");
+}
+
+// ============================================================================ depthwise k x k, stride 1
+// thread = (pixel, 8-channel vector); taps come through L1/L2 (activation tiles of neighbouring threads overlap).
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(int B, int H, int W, int C, int act, const T* __restrict__ x, int xCs,
+                                                     const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int yCs) {
+  const int cv = C >> 3;
+  const long total = (long)B * H * W * cv;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = (int)(idx % cv) * 8;
+  long m = idx / cv;
+  const int ox = (int)(m % W);
+  const long t = m / W;
+  const int oy = (int)(t % H);
+  const int b = (int)(t / H);
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = bias ? bias[c8 + i] : 0.f;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int iy = oy - K / 2 + ky;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int ix = ox - K / 2 + kx;
+      if (ix < 0 || ix >= W) continue;
+      Vec8<T> xv, wv;
+      xv.load(x + (((long)b * H + iy) * W + ix) * xCs + c8);
+      wv.load(w + (ky * K + kx) * C + c8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += xv.get(i) * wv.get(i);
+    }
+  }
+  Vec8<T> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.set(i, ey_act(acc[i], act));
+  o.store(y + m * yCs + c8);
+}
+
+template <typename T>
+static int dw_launch(int B, int H, int W, int C, int k, int act, const void* x, int xCs, const void* w, const float* bias, void* y, int yCs, hipStream_t st) {
+  const long total = (long)B * H * W * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256));
+#define DW(K) hipLaunchKernelGGL((dwconv_kernel<T, K>), grid, dim3(256), 0, st, B, H, W, C, act, (const T*)x, xCs, (const T*)w, bias, (T*)y, yCs)
+  if (k == 3) DW(3); else if (k == 5) DW(5); else DW(7);
+#undef DW
+  EY_LAUNCH_CHECK("ey_dwconv");
+  return EY_OK;
+}
+
+extern "C" int ey_dwconv(int dtype, int B, int H, int W, int C, int k, int act, const void* x, int x_cstride, const void* w,
+                         const float* bias, void* y, int y_cstride, ey_stream_t stream) {
+  EY_CHECK(x && w && y, "dwconv: null pointer");
+  EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "dwconv: bad dtype");
+  EY_CHECK(k == 3 || k == 5 || k == 7, "dwconv: k=%d (3,5,7)", k);
+  EY_CHECK(C > 0 && C % 8 == 0, "dwconv: C=%d must be a multiple of 8 (use ey_conv2d_direct)", C);
+  const int es = dtype == EY_F16 ? 2 : 4;
+  EY_CHECK(x_cstride >= C && y_cstride >= C && (x_cstride * es) % 16 == 0 && (y_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(y, 16) && ey_aligned(w, 16),
+           "dwconv: views must be 16-byte aligned");
+  return dtype == EY_F16 ? dw_launch<f16>(B, H, W, C, k, act, x, x_cstride, w, bias, y, y_cstride, (hipStream_t)stream)
+                         : dw_launch<float>(B, H, W, C, k, act, x, x_cstride, w, bias, y, y_cstride, (hipStream_t)stream);
+}
+
+// ============================================================================ Haar DWT (one level)
+// taps = float32(1/sqrt2)^2 = 0.49999997 as the reference's pywt-derived conv weights (block.py:3597-3606)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void dwt_kernel(int B, int H, int W, int C, const T* __restrict__ x, int xCs, T* __restrict__ y, int yCs) {
+  const int Ho = H >> 1, Wo = W >> 1, cv = C / V;
+  const long total = (long)B * Ho * Wo * cv;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c0 = (int)(idx % cv) * V;
+  long m = idx / cv;
+  const int ox = (int)(m % Wo);
+  const long t = m / Wo;
+  const int oy = (int)(t % Ho);
+  const int b = (int)(t / Ho);
+  const T* p00 = x + (((long)b * H + 2 * oy) * W + 2 * ox) * xCs + c0;
+  const T* p01 = p00 + xCs;
+  const T* p10 = p00 + (long)W * xCs;
+  const T* p11 = p10 + xCs;
+  T* yp = y + m * yCs + c0;
+  const float s = 0.70710678118654752440f, tp = s * s;
+  if constexpr (V == 8) {
+    Vec8<T> a, bq, c, d, ll, lh, hl, hh;
+    a.load(p00); bq.load(p01); c.load(p10); d.load(p11);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float fa = a.get(i) * tp, fb = bq.get(i) * tp, fc = c.get(i) * tp, fd = d.get(i) * tp;
+      ll.set(i, (fa + fb) + (fc + fd));
+      lh.set(i, (fa - fb) + (fc - fd));
+      hl.set(i, (fa + fb) - (fc + fd));
+      hh.set(i, (fa - fb) - (fc - fd));
+    }
+    ll.store(yp); lh.store(yp + C); hl.store(yp + 2 * C); hh.store(yp + 3 * C);
+  } else {
+    const float fa = to_f(*p00) * tp, fb = to_f(*p01) * tp, fc = to_f(*p10) * tp, fd = to_f(*p11) * tp;
+    yp[0] = from_f<T>((fa + fb) + (fc + fd));
+    yp[C] = from_f<T>((fa - fb) + (fc - fd));
+    yp[2 * C] = from_f<T>((fa + fb) - (fc + fd));
+    yp[3 * C] = from_f<T>((fa - fb) - (fc - fd));
+  }
+}
+
+extern "C" int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y, int y_cstride, ey_stream_t stream) {
+  EY_CHECK(x && y, "dwt: null pointer");
+  EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "dwt: bad dtype");
+  EY_CHECK(B > 0 && H >= 2 && W >= 2 && C > 0, "dwt: bad extent");
+  EY_CHECK(x_cstride >= C && y_cstride >= 4 * C, "dwt: cstride");
+  const int es = dtype == EY_F16 ? 2 : 4;
+  const bool vec = C % 8 == 0 && (x_cstride * es) % 16 == 0 && (y_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(y, 16);
+  const long total = (long)B * (H / 2) * (W / 2) * (vec ? C / 8 : C);
+  dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EY_F16) {
+    if (vec) hipLaunchKernelGGL((dwt_kernel<f16, 8>), grid, dim3(256), 0, st, B, H, W, C, (const f16*)x, x_cstride, (f16*)y, y_cstride);
+    else hipLaunchKernelGGL((dwt_kernel<f16, 1>), grid, dim3(256), 0, st, B, H, W, C, (const f16*)x, x_cstride, (f16*)y, y_cstride);
+  } else {
+    if (vec) hipLaunchKernelGGL((dwt_kernel<float, 8>), grid, dim3(256), 0, st, B, H, W, C, (const float*)x, x_cstride, (float*)y, y_cstride);
+    else hipLaunchKernelGGL((dwt_kernel<float, 1>), grid, dim3(256), 0, st, B, H, W, C, (const float*)x, x_cstride, (float*)y, y_cstride);
+  }
+  EY_LAUNCH_CHECK("ey_dwt_haar");
+  return EY_OK;
+}
+
+// ============================================================================ SPPF: three chained 5x5 max pools
+// block = one image x one 8-channel vector; the whole (H x W x 8ch) plane lives in LDS; separable max (row pass,
+// column pass) applied three times, exactly the reference's chain (padding acts as -inf).
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_kernel(int H, int W, int C, const T* __restrict__ x, int xCs, T* __restrict__ y1, T* __restrict__ y2,
+                                                   T* __restrict__ y3, int yCs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  Vec8<T>* A = reinterpret_cast<Vec8<T>*>(smem);
+  Vec8<T>* Bf = A + H * W;
+  const int cv = C >> 3;
+  const int b = blockIdx.x / cv, c8 = (blockIdx.x % cv) * 8;
+  const long base = (long)b * H * W;
+  for (int i = threadIdx.x; i < H * W; i += blockDim.x) A[i].load(x + (base + i) * xCs + c8);
+  __syncthreads();
+  T* outs[3] = {y1, y2, y3};
+  for (int pass = 0; pass < 3; ++pass) {
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {  // rows
+      const int yy = i / W, xx = i - yy * W;
+      Vec8<T> mx = A[i];
+      for (int dx = -2; dx <= 2; ++dx) {
+        const int x2 = xx + dx;
+        if (dx == 0 || x2 < 0 || x2 >= W) continue;
+        const Vec8<T>& o = A[yy * W + x2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx.set(k, fmaxf(mx.get(k), o.get(k)));
+      }
+      Bf[i] = mx;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {  // columns
+      const int yy = i / W, xx = i - yy * W;
+      Vec8<T> mx = Bf[i];
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int y2 = yy + dy;
+        if (dy == 0 || y2 < 0 || y2 >= H) continue;
+        const Vec8<T>& o = Bf[y2 * W + xx];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx.set(k, fmaxf(mx.get(k), o.get(k)));
+      }
+      mx.store(outs[pass] + (base + i) * yCs + c8);
+      A[i] = mx;  // only element i of A is touched by this thread: no hazard with the column reads of Bf
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ey_sppf_pool(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y1, void* y2, void* y3, int y_cstride,
+                            ey_stream_t stream) {
+  EY_CHECK(x && y1 && y2 && y3, "sppf: null pointer");
+  EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "sppf: bad dtype");
+  EY_CHECK(C > 0 && C % 8 == 0, "sppf: C=%d must be a multiple of 8", C);
+  const int es = dtype == EY_F16 ? 2 : 4;
+  const size_t lds = (size_t)H * W * 8 * es * 2;
+  EY_CHECK(lds <= 160 * 1024, "sppf: %dx%d plane does not fit LDS (%zu B)", H, W, lds);
+  EY_CHECK((x_cstride * es) % 16 == 0 && (y_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(y1, 16) && ey_aligned(y2, 16) && ey_aligned(y3, 16),
+           "sppf: views must be 16-byte aligned");
+  dim3 grid(B * (C / 8));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EY_F16) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)sppf_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ey_set_error(EY_ELAUNCH, "cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(sppf_kernel<f16>, grid, dim3(256), lds, st, H, W, C, (const f16*)x, x_cstride, (f16*)y1, (f16*)y2, (f16*)y3, y_cstride);
+  } else {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)sppf_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ey_set_error(EY_ELAUNCH, "cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(sppf_kernel<float>, grid, dim3(256), lds, st, H, W, C, (const float*)x, x_cstride, (float*)y1, (float*)y2, (float*)y3, y_cstride);
+  }
+  EY_LAUNCH_CHECK("ey_sppf_pool");
+  return EY_OK;
+}
+
+// ============================================================================ slice copy (+ nearest x2) and layout transposes
+template <typename T, int V>
+__global__ __launch_bounds__(256) void copy_kernel(int B, int H, int W, int C, int up, const T* __restrict__ s, int sCs, T* __restrict__ d, int dCs) {
+  const int cv = C / V;
+  const long total = (long)B * H * W * cv;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c0 = (int)(idx % cv) * V;
+  long m = idx / cv;
+  const int xx = (int)(m % W);
+  const long t = m / W;
+  const int yy = (int)(t % H);
+  const int b = (int)(t / H);
+  const int Hs = H >> up, Ws = W >> up;
+  const T* sp = s + (((long)b * Hs + (yy >> up)) * Ws + (xx >> up)) * sCs + c0;
+  T* dp = d + m * dCs + c0;
+  if constexpr (V == 8) { Vec8<T> v; v.load(sp); v.store(dp); }
+  else *dp = *sp;
+}
+
+extern "C" int ey_copy_nhwc(int dtype, int B, int H, int W, int C, int up, const void* src, int src_cstride, void* dst, int dst_cstride, ey_stream_t stream) {
+  EY_CHECK(src && dst, "copy: null pointer");
+  EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "copy: bad dtype");
+  EY_CHECK(up == 0 || (up == 1 && H % 2 == 0 && W % 2 == 0), "copy: up=%d needs even output extent", up);
+  EY_CHECK(src_cstride >= C && dst_cstride >= C, "copy: cstride");
+  const int es = dtype == EY_F16 ? 2 : 4;
+  const bool vec = C % 8 == 0 && (src_cstride * es) % 16 == 0 && (dst_cstride * es) % 16 == 0 && ey_aligned(src, 16) && ey_aligned(dst, 16);
+  const long total = (long)B * H * W * (vec ? C / 8 : C);
+  dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EY_F16) {
+    if (vec) hipLaunchKernelGGL((copy_kernel<f16, 8>), grid, dim3(256), 0, st, B, H, W, C, up, (const f16*)src, src_cstride, (f16*)dst, dst_cstride);
+    else hipLaunchKernelGGL((copy_kernel<f16, 1>), grid, dim3(256), 0, st, B, H, W, C, up, (const f16*)src, src_cstride, (f16*)dst, dst_cstride);
+  } else {
+    if (vec) hipLaunchKernelGGL((copy_kernel<float, 8>), grid, dim3(256), 0, st, B, H, W, C, up, (const float*)src, src_cstride, (float*)dst, dst_cstride);
+    else hipLaunchKernelGGL((copy_kernel<float, 1>), grid, dim3(256), 0, st, B, H, W, C, up, (const float*)src, src_cstride, (float*)dst, dst_cstride);
+  }
+  EY_LAUNCH_CHECK("ey_copy_nhwc");
+  return EY_OK;
+}
+
+// tiled transpose through LDS: planes of (C x HW) <-> (HW x C)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T* __restrict__ s, long sBatch, int sRow, T* __restrict__ d, long dBatch, int dRow) {
+  // s[b][r][c] (row stride sRow) -> d[b][c][r] (row stride dRow)
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = s[b * sBatch + (long)r * sRow + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) d[b * dBatch + (long)c * dRow + r] = tile[tx][i];
+  }
+}
+
+extern "C" int ey_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const void* src, void* dst, int dst_cstride, ey_stream_t stream) {
+  EY_CHECK(src && dst && dst_cstride >= C, "nchw_to_nhwc: bad args");
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  if (dtype == EY_F16) hipLaunchKernelGGL(transpose_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, C, HW, (const f16*)src, (long)C * HW, HW, (f16*)dst, (long)HW * dst_cstride, dst_cstride);
+  else if (dtype == EY_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, C, HW, (const float*)src, (long)C * HW, HW, (float*)dst, (long)HW * dst_cstride, dst_cstride);
+  else return ey_set_error(EY_EINVAL, "nchw_to_nhwc: bad dtype");
+  EY_LAUNCH_CHECK("ey_nchw_to_nhwc");
+  return EY_OK;
+}
+
+extern "C" int ey_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* src, int src_cstride, void* dst, ey_stream_t stream) {
+  EY_CHECK(src && dst && src_cstride >= C, "nhwc_to_nchw: bad args");
+  const int HW = H * W;
+  dim3 grid((C + 31) / 32, (HW + 31) / 32, B);
+  if (dtype == EY_F16) hipLaunchKernelGGL(transpose_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, HW, C, (const f16*)src, (long)HW * src_cstride, src_cstride, (f16*)dst, (long)C * HW, HW);
+  else if (dtype == EY_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, HW, C, (const float*)src, (long)HW * src_cstride, src_cstride, (float*)dst, (long)C * HW, HW);
+  else return ey_set_error(EY_EINVAL, "nhwc_to_nchw: bad dtype");
+  EY_LAUNCH_CHECK("ey_nhwc_to_nchw");
+  return EY_OK;
+}

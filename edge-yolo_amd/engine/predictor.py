@@ -1,0 +1,147 @@
+"""Predict loop for the detect task: preprocess -> inference -> postprocess, mirroring the reference's
+engine/predictor.py (`BasePredictor.preprocess/inference/postprocess/stream_inference` :116-304) and
+models/yolo/detect/predict.py (`DetectionPredictor.postprocess` :23-41).
+
+MI355X-native execution model: the whole per-batch device work (stem ... head decode, NMS) is launched on one HIP
+stream and, for a fixed (batch, H, W, dtype), captured ONCE into a hipGraph and replayed (the reference re-dispatches
+~300 ATen ops from Python per batch).  NMS results come back as one fixed-size (B,max_det,6)+(B,) device buffer,
+so there is exactly one D2H copy per batch.
+"""
+import threading
+import time
+
+import numpy as np
+import torch
+
+from .results import Results
+from ..utils import ops
+
+
+class Profile:
+    """Wall timer with device sync (reference utils/ops.py:17-62)."""
+
+    def __init__(self, device=None):
+        self.t, self.dt, self.device = 0.0, 0.0, device
+
+    def __enter__(self):
+        self.start = self.time()
+        return self
+
+    def __exit__(self, *a):
+        self.dt = self.time() - self.start
+        self.t += self.dt
+
+    def time(self):
+        if self.device is not None and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return time.perf_counter()
+
+
+class GraphRunner:
+    """Captures `fn(static_input) -> tuple of tensors` into a HIP graph per input signature and replays it."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn, self.warmup, self.graphs = fn, warmup, {}
+
+    def __call__(self, x):
+        key = (tuple(x.shape), x.dtype, x.device)
+        g = self.graphs.get(key)
+        if g is None:
+            static_in = x.clone()
+            s = torch.cuda.Stream(device=x.device)
+            s.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(s):
+                for _ in range(self.warmup):  # packs weights, sizes allocator pools
+                    out = self.fn(static_in)
+            torch.cuda.current_stream(x.device).wait_stream(s)
+            torch.cuda.synchronize(x.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.fn(static_in)
+            g = self.graphs[key] = (graph, static_in, out)
+        graph, static_in, out = g
+        static_in.copy_(x, non_blocking=True)
+        graph.replay()
+        return out
+
+
+class DetectionPredictor:
+    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True):
+        self.model, self.device, self.half = model, device, half
+        self.conf, self.iou, self.max_det, self.agnostic_nms, self.classes = conf, iou, max_det, agnostic_nms, classes
+        self._lock = threading.Lock()
+        self.runner = GraphRunner(self._device_step) if graph else self._device_step
+
+    # ---- device side (captured)
+    def _device_step(self, im):
+        preds = self.model(im)
+        pred = preds[0] if isinstance(preds, (list, tuple)) else preds
+        boxes, count, index = ops.nms_device(pred, self.conf, self.iou, self.classes, self.agnostic_nms, self.max_det)
+        return boxes, count, index, pred
+
+    def preprocess(self, im):
+        """Tensor sources: BCHW float in [0,1] (reference LoadTensor, data/loaders.py:516-586).  ndarray / list sources:
+        HWC uint8 BGR images, letterboxed to a common stride-32 shape on the host (reference predictor.py:116-161)."""
+        if not isinstance(im, torch.Tensor):
+            im = self._letterbox_batch(im)
+        if im.dim() == 3:
+            im = im[None]
+        if im.dim() != 4 or im.shape[2] % 32 or im.shape[3] % 32:
+            raise ValueError(f"input tensor should be BCHW with H,W multiples of 32, got {tuple(im.shape)}")
+        if im.is_floating_point() and im.numel() and float(im.max()) > 1.0 + 1e-5:
+            raise ValueError("torch.Tensor inputs should be normalized 0.0-1.0")
+        im = im.to(self.device)
+        return (im.half() if self.half else im.float()).contiguous()
+
+    def _letterbox_batch(self, ims, new_shape=640, stride=32, pad=114):
+        ims = ims if isinstance(ims, (list, tuple)) else [ims]
+        self._orig = [np.asarray(a) for a in ims]
+        out = []
+        for a in self._orig:
+            h, w = a.shape[:2]
+            r = min(new_shape / h, new_shape / w)
+            nh, nw = int(round(h * r)), int(round(w * r))
+            t = torch.from_numpy(np.ascontiguousarray(a[..., ::-1])).permute(2, 0, 1)[None].float()  # BGR->RGB
+            if (nh, nw) != (h, w):
+                t = torch.nn.functional.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False)
+            canvas = torch.full((1, 3, new_shape, new_shape), float(pad))
+            top, left = int(round((new_shape - nh) / 2 - 0.1)), int(round((new_shape - nw) / 2 - 0.1))
+            canvas[:, :, top:top + nh, left:left + nw] = t
+            out.append(canvas / 255.0)
+        return torch.cat(out)
+
+    def __call__(self, source):
+        with self._lock:
+            self._orig = None
+            prof = (Profile(self.device), Profile(self.device), Profile(self.device))
+            with prof[0]:
+                im = self.preprocess(source)
+            with prof[1]:
+                boxes, count, index, pred = self.runner(im)
+            with prof[2]:
+                results = self.postprocess(boxes, count, im, source)
+            n = len(results)
+            for r in results:
+                r.speed = {"preprocess": prof[0].dt * 1e3 / n, "inference": prof[1].dt * 1e3 / n, "postprocess": prof[2].dt * 1e3 / n}
+            return results
+
+    def postprocess(self, boxes, count, img, source):
+        """reference detect/predict.py:23-41: per image rows -> scale_boxes to the original shape -> Results."""
+        n = count.tolist()
+        boxes = boxes.clone()
+        results = []
+        names = self.model.names
+        for i in range(len(n)):
+            det = boxes[i, : n[i]]
+            if self._orig is not None:
+                orig = self._orig[i]
+                det[:, :4] = ops.scale_boxes(img.shape[2:], det[:, :4], orig.shape)
+            else:  # tensor source: original image == network input
+                orig = None
+                det[:, :4] = ops.clip_boxes(det[:, :4], img.shape[2:])
+            r = Results(orig, path=f"image{i}.jpg", names=names, boxes=det)
+            if orig is None:
+                r.orig_shape = tuple(img.shape[2:])
+                r.boxes.orig_shape = r.orig_shape
+            results.append(r)
+        return results

@@ -1,0 +1,274 @@
+"""Tensor-level wrappers over the C ABI: take logical-NCHW torch tensors (NHWC memory), hand plain pointers /
+strides to libedgeyolo_hip.so on the current HIP stream.  No arithmetic happens in Python or in torch here."""
+import ctypes
+
+import torch
+
+from .. import _lib as L
+
+
+def _dev_key(x, tag=""):
+    return (tag, x.dtype, x.device)
+
+
+def pack_conv_weight(w_oihw, dtype, device):
+    """fp32 OIHW -> packed MFMA layout (host side, ey_conv_pack_weight) -> device."""
+    w = w_oihw.detach().float().cpu().contiguous()
+    co, ci, k, _ = w.shape
+    code = L.dtype_code(dtype)
+    nbytes = L.lib().ey_conv_packed_bytes(code, co, ci, k)
+    buf = torch.empty(nbytes, dtype=torch.uint8)
+    L.check(L.lib().ey_conv_pack_weight(code, co, ci, k, w.data_ptr(), buf.data_ptr(), nbytes), "conv_pack_weight")
+    return buf.to(device)
+
+
+def igemm_ok(srcs, k, s, p):
+    if k not in (1, 3) or s not in (1, 2) or p != k // 2:
+        return False
+    for t in srcs:
+        es = t.element_size()
+        if t.shape[1] % 8 or (L.cstride(t) * es) % 16 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=None, addz=None, out_scale=1.0,
+           ngroup=1, src_gstride=0, y_gstride=0, group_C=None):
+    """y = res + out_scale*act(conv(cat(srcs)) + bias + up2x(addz)).  srcs: list of 1-2 logical-NCHW tensors
+    (source i is read through a nearest x2 upsample when up[i]).  With ngroup>1 `srcs[0]`/`out` are the group-0
+    slices and *_gstride the element offsets between groups (channel count per group = group_C)."""
+    x0 = srcs[0]
+    L.require_device(x0, "conv2d")
+    srcs = [L.as_nhwc(t) for t in srcs]
+    up = up or [0] * len(srcs)
+    B = srcs[0].shape[0]
+    H = srcs[0].shape[2] << up[0]
+    W = srcs[0].shape[3] << up[0]
+    for t, u in zip(srcs, up):
+        if (t.shape[0], t.shape[2] << u, t.shape[3] << u) != (B, H, W) or t.dtype != x0.dtype:
+            raise ValueError(f"conv2d: sources disagree: {[tuple(t.shape) for t in srcs]} up={up}")
+    cin = sum(t.shape[1] for t in srcs)
+    if len(srcs) > 2 or not igemm_ok(srcs, k, s, p):
+        if len(srcs) != 1 or up[0] or addz is not None or ngroup != 1 or out_scale != 1.0:
+            raise NotImplementedError("this conv shape needs the generic direct kernel, which takes a single plain source")
+        return conv2d_direct(mod, srcs[0], folded_fn, k, s, p, 1, act, out=out, res=res, tag=tag)
+    dtype, dev = x0.dtype, x0.device
+
+    def build():
+        w, b = folded_fn()
+        if w.shape[1] != cin or w.shape[2] != k:
+            raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match Cin={cin} k={k}")
+        return pack_conv_weight(w, dtype, dev), (b.to(dev).contiguous() if b is not None else None), w.shape[0]
+
+    wp, bias, cout = mod._packed(_dev_key(x0, "igemm" + tag), build)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if out is None:
+        out = L.empty_nhwc(B, cout * (ngroup if y_gstride == 0 and ngroup > 1 else 1), Ho, Wo, dtype, dev)
+    elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, Ho, Wo) or out.dtype != dtype:
+        raise ValueError(f"conv2d: out= must be an NHWC view of shape {(B, cout, Ho, Wo)} {dtype}, got {tuple(out.shape)} {out.dtype}")
+    d = L.ConvDesc()
+    d.dtype = L.dtype_code(dtype)
+    d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = B, H, W, Ho, Wo, cout
+    d.k, d.stride, d.pad, d.act, d.nsrc = k, s, p, act, len(srcs)
+    for i, t in enumerate(srcs):
+        d.src[i] = t.data_ptr()
+        d.src_C[i] = group_C if (group_C and i == 0) else t.shape[1]
+        d.src_cstride[i] = L.cstride(t)
+        d.src_up[i] = up[i]
+    d.w = wp.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.y, d.y_cstride = out.data_ptr(), L.cstride(out)
+    if res is not None:
+        res = L.as_nhwc(res)
+        if tuple(res.shape) != (B, cout, Ho, Wo) or res.dtype != dtype:
+            raise ValueError("conv2d: residual shape/dtype mismatch")
+        d.res, d.res_cstride = res.data_ptr(), L.cstride(res)
+    d.out_scale = float(out_scale)
+    if addz is not None:
+        addz = L.as_nhwc(addz)
+        if tuple(addz.shape[:2]) != (B, cout) or addz.dtype != dtype:
+            raise ValueError("conv2d: addz batch/channel/dtype mismatch")
+        d.addz, d.addz_cstride, d.addz_H, d.addz_W = addz.data_ptr(), L.cstride(addz), addz.shape[2], addz.shape[3]
+    d.ngroup, d.src_gstride, d.y_gstride = ngroup, src_gstride, y_gstride
+    L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
+    return out
+
+
+def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""):
+    L.require_device(x, "conv2d_direct")
+    if res is not None:
+        raise NotImplementedError("residual add is only fused into the MFMA conv")
+    x = L.as_nhwc(x)
+    B, cin, H, W = x.shape
+
+    def build():
+        w, b = folded_fn()
+        return w.to(x.device).contiguous(), (b.to(x.device).contiguous() if b is not None else None)
+
+    w, bias = mod._packed(_dev_key(x, "direct" + tag), build)
+    cout = w.shape[0]
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if out is None:
+        out = L.empty_nhwc(B, cout, Ho, Wo, x.dtype, x.device)
+    d = L.ConvDirectDesc()
+    d.dtype = L.dtype_code(x.dtype)
+    d.B, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = B, H, W, cin, Ho, Wo, cout
+    d.k, d.stride, d.pad, d.groups, d.act = k, s, p, g, act
+    d.x, d.x_cstride = x.data_ptr(), L.cstride(x)
+    d.w_oihw = w.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.y, d.y_cstride = out.data_ptr(), L.cstride(out)
+    L.check(L.lib().ey_conv2d_direct(ctypes.byref(d), L.stream()), "ey_conv2d_direct")
+    return out
+
+
+def stem_conv(mod, x, folded_fn, act, out_dtype, out=None):
+    """3x3/s2 conv straight from the NCHW-contiguous image (layer 0)."""
+    L.require_device(x, "stem_conv")
+    B, cin, H, W = x.shape
+
+    def build():
+        w, b = folded_fn()
+        return w.to(x.device).contiguous(), b.to(x.device).contiguous()
+
+    w, bias = mod._packed(("stem", x.device), build)
+    cout = w.shape[0]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = L.empty_nhwc(B, cout, Ho, Wo, out_dtype, x.device)
+    L.check(L.lib().ey_stem_conv(L.dtype_code(x.dtype), L.dtype_code(out_dtype), B, cin, H, W, cout, act, x.data_ptr(), w.data_ptr(),
+                                 bias.data_ptr(), out.data_ptr(), L.cstride(out), L.stream()), "ey_stem_conv")
+    return out
+
+
+def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
+    L.require_device(x, "dwconv")
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    es = x.element_size()
+    if c % 8 or (L.cstride(x) * es) % 16 or x.data_ptr() % 16:
+        return conv2d_direct(mod, x, folded_fn, k, 1, k // 2, c, act, out=out, tag=tag)
+
+    def build():
+        w, b = folded_fn()  # (C,1,k,k)
+        wk = w.view(c, k, k).permute(1, 2, 0).contiguous().to(device=x.device, dtype=x.dtype)  # [k][k][C]
+        return wk, (b.to(x.device).contiguous() if b is not None else None)
+
+    wk, bias = mod._packed(_dev_key(x, "dw" + tag), build)
+    if out is None:
+        out = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
+    L.check(L.lib().ey_dwconv(L.dtype_code(x.dtype), B, H, W, c, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
+                              bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out), L.stream()), "ey_dwconv")
+    return out
+
+
+def dwt_haar(x, out=None):
+    """(B,C,H,W) -> (B,4C,H/2,W/2) with channel blocks LL|LH|HL|HH."""
+    L.require_device(x, "dwt_haar")
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    if out is None:
+        out = L.empty_nhwc(B, 4 * c, H // 2, W // 2, x.dtype, x.device)
+    L.check(L.lib().ey_dwt_haar(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), out.data_ptr(), L.cstride(out), L.stream()), "ey_dwt_haar")
+    return out
+
+
+def sppf_pool(x, y1, y2, y3):
+    L.require_device(x, "sppf_pool")
+    B, c, H, W = x.shape
+    cs = L.cstride(y1)
+    if L.cstride(y2) != cs or L.cstride(y3) != cs:
+        raise ValueError("sppf_pool: outputs must share one pixel stride")
+    L.check(L.lib().ey_sppf_pool(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), cs,
+                                 L.stream()), "ey_sppf_pool")
+
+
+def copy_slice(src, dst, up=0):
+    """dst[b,c,y,x] = src[b,c,y>>up,x>>up] (both NHWC views)."""
+    B, c, H, W = dst.shape
+    L.check(L.lib().ey_copy_nhwc(L.dtype_code(dst.dtype), B, H, W, c, up, src.data_ptr(), L.cstride(src), dst.data_ptr(), L.cstride(dst), L.stream()),
+            "ey_copy_nhwc")
+    return dst
+
+
+def concat(xs):
+    xs = [L.as_nhwc(t) for t in xs]
+    L.require_device(xs[0], "concat")
+    B, _, H, W = xs[0].shape
+    out = L.empty_nhwc(B, sum(t.shape[1] for t in xs), H, W, xs[0].dtype, xs[0].device)
+    c0 = 0
+    for t in xs:
+        if (t.shape[0], t.shape[2], t.shape[3]) != (B, H, W) or t.dtype != out.dtype:
+            raise ValueError(f"concat: incompatible inputs {[tuple(t.shape) for t in xs]}")
+        copy_slice(t, out[:, c0:c0 + t.shape[1]])
+        c0 += t.shape[1]
+    return out
+
+
+def upsample2x(x):
+    x = L.as_nhwc(x)
+    L.require_device(x, "upsample2x")
+    B, c, H, W = x.shape
+    return copy_slice(x, L.empty_nhwc(B, c, 2 * H, 2 * W, x.dtype, x.device), up=1)
+
+
+def to_nchw_contiguous(x):
+    """NHWC view -> plain contiguous NCHW tensor (what a foreign caller expects from .contiguous())."""
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    out = torch.empty((B, c, H, W), dtype=x.dtype, device=x.device)
+    L.check(L.lib().ey_nhwc_to_nchw(L.dtype_code(x.dtype), B, c, H, W, x.data_ptr(), L.cstride(x), out.data_ptr(), L.stream()), "ey_nhwc_to_nchw")
+    return out
+
+
+def linear_attention(qkv, heads, out=None):
+    """qkv (B,3C,H,W) [q|k|v] -> (B,C,H,W)."""
+    L.require_device(qkv, "linear_attention")
+    qkv = L.as_nhwc(qkv)
+    B, c3, H, W = qkv.shape
+    c = c3 // 3
+    if out is None:
+        out = L.empty_nhwc(B, c, H, W, qkv.dtype, qkv.device)
+    L.check(L.lib().ey_linear_attention(L.dtype_code(qkv.dtype), B, H * W, c, heads, qkv.data_ptr(), L.cstride(qkv), out.data_ptr(), L.cstride(out),
+                                        L.stream()), "ey_linear_attention")
+    return out
+
+
+def softmax_attention(qkv, heads, kd, hd, scale, out=None):
+    L.require_device(qkv, "softmax_attention")
+    qkv = L.as_nhwc(qkv)
+    B, _, H, W = qkv.shape
+    if out is None:
+        out = L.empty_nhwc(B, heads * hd, H, W, qkv.dtype, qkv.device)
+    L.check(L.lib().ey_softmax_attention(L.dtype_code(qkv.dtype), B, H * W, heads, kd, hd, float(scale), qkv.data_ptr(), L.cstride(qkv),
+                                         out.data_ptr(), L.cstride(out), L.stream()), "ey_softmax_attention")
+    return out
+
+
+def head_decode(box, cls, stride, q, pred, a_off):
+    """One pyramid level of the fused DGQP + DFL + decode; q = (w1[hid,20], b1, w2[hid], b2) fp32 device tensors or None."""
+    L.require_device(box, "head_decode")
+    B, _, H, W = box.shape
+    nc = cls.shape[1]
+    qa = [t.data_ptr() for t in q] if q is not None else [None] * 4
+    hid = q[0].shape[0] if q is not None else 0
+    L.check(L.lib().ey_head_decode(L.dtype_code(box.dtype), B, H, W, nc, float(stride), box.data_ptr(), L.cstride(box), cls.data_ptr(), L.cstride(cls),
+                                   qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
+
+
+def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None):
+    """pred fp32 (B,4+nc,A) contiguous -> (boxes (B,max_det,6) fp32, count (B,) int32, index (B,max_det) int32)."""
+    L.require_device(pred, "nms")
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        raise ValueError("nms: pred must be a contiguous float32 (B,4+nc,A) tensor")
+    B, no, A = pred.shape
+    dev = pred.device
+    boxes = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    index = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    nbytes = L.lib().ey_nms_workspace_bytes(B, A)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)),
+                           class_mask.data_ptr() if class_mask is not None else None, boxes.data_ptr(), count.data_ptr(), index.data_ptr(),
+                           ws.data_ptr(), nbytes, L.stream()), "ey_nms")
+    return boxes, count, index

@@ -1,0 +1,170 @@
+"""Detection heads, HIP-backed: `Detect` (reference head.py:38-189), `GF2Detect` (:194-345), `GFLHeadv2_uniH`
+(:827-908).  Same constructor signatures / attribute names / state_dict keys.  The towers are MFMA convs and
+depthwise kernels; everything after them (DGQP statistics + quality FCs, DFL softmax-expectation, anchor decode,
+score modulation) is ONE fused kernel per pyramid level writing the (B, 4+nc, A) fp32 prediction tensor.
+"""
+import copy
+import math
+
+import torch
+import torch.nn as nn
+
+from .block import DFL
+from .conv import Conv, DWConv, _Packed, fold_bn
+from .. import _ops as ops
+from ... import _lib as L
+
+__all__ = ("Detect", "GF2Detect", "GFLHeadv2_uniH")
+
+
+class _Plain(_Packed):
+    """Weights of a bare nn.Conv2d(+bias) 1x1 tower tail, packed for the MFMA conv."""
+
+    def __init__(self, conv):
+        super().__init__()
+        self.__dict__["_ref"] = conv  # not registered: the nn.Conv2d stays where the reference keeps it
+
+    def run(self, x, out):
+        c = self._ref
+        return ops.conv2d(self, [x], lambda: fold_bn(c.weight, c.bias, None), 1, 1, 0, L.ACT_NONE, out=out)
+
+
+class Detect(nn.Module):
+    """YOLO Detect head (reference head.py:38-189)."""
+
+    dynamic = False
+    export = False
+    format = None
+    end2end = False
+    max_det = 300
+    shape = None
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+    legacy = False
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], min(self.nc, 100))
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = (
+            nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, self.nc, 1)) for x in ch)
+            if self.legacy
+            else nn.ModuleList(
+                nn.Sequential(nn.Sequential(DWConv(x, x, 3), Conv(x, c3, 1)), nn.Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)),
+                              nn.Conv2d(c3, self.nc, 1))
+                for x in ch)
+        )
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+        self._tails = {}
+
+    # ---- towers
+    def _tail(self, conv):
+        t = self._tails.get(id(conv))
+        if t is None:
+            t = self._tails[id(conv)] = _Plain(conv)
+        return t
+
+    def _apply(self, fn, *a, **k):
+        self._tails = {}
+        self._stride_f = None
+        return super()._apply(fn, *a, **k)
+
+    def _towers(self, i, x, raw):
+        """box logits -> raw[:, :64], class logits -> raw[:, 64:]."""
+        b = self.cv2[i]
+        self._tail(b[2]).run(b[1](b[0](x)), raw[:, :4 * self.reg_max])
+        c = self.cv3[i]
+        t = x
+        for j in range(len(c) - 1):
+            t = c[j](t)
+        self._tail(c[-1]).run(t, raw[:, 4 * self.reg_max:])
+
+    def _quality_params(self, i, device):
+        return None
+
+    def forward(self, x):
+        if self.end2end:
+            raise NotImplementedError("end2end (NMS-free) heads are outside the built path")
+        if self.training:
+            raise RuntimeError("edge-yolo_amd implements the inference forward only: call model.eval()")
+        if self.reg_max != 16:
+            raise NotImplementedError("the decode kernel is built for reg_max=16")
+        xs = [L.as_nhwc(t) for t in x]
+        B, dev, dt = xs[0].shape[0], xs[0].device, xs[0].dtype
+        A = sum(t.shape[2] * t.shape[3] for t in xs)
+        pred = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=dev)
+        a_off = 0
+        if getattr(self, "_stride_f", None) is None:
+            self._stride_f = [float(s) for s in self.stride]  # host copy once (no D2H inside a captured graph)
+        for i, t in enumerate(xs):
+            H, W = t.shape[2:]
+            raw = L.empty_nhwc(B, (self.no + 7) // 8 * 8, H, W, dt, dev)[:, :self.no]  # pixel stride kept 16-byte aligned for any nc
+            self._towers(i, t, raw)
+            ops.head_decode(raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), pred, a_off)
+            a_off += H * W
+            x[i] = raw
+        return pred if self.export else (pred, x)
+
+    def bias_init(self):
+        """reference head.py:150-161 (needs self.stride)."""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
+        self._tails = {}
+
+
+class GF2Detect(Detect):
+    """GFLv2-style quality head on top of Detect (reference head.py:194-345): q = DGQP(softmax(box logits)),
+    score = sigmoid(cls) * clamp(q, 1e-6, 1-1e-6)."""
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__(nc, ch)
+        self.reg_topk = 4
+        self.add_mean = True
+        self.reg_channels = 64
+        self.apply_quality_in_inference = True
+        in_stat = 4 * (self.reg_topk + (1 if self.add_mean else 0))
+        self.reg_conf = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(in_stat, self.reg_channels, 1, bias=True), nn.ReLU(inplace=True), nn.Conv2d(self.reg_channels, 1, 1, bias=True),
+                          nn.Sigmoid()) for _ in ch)
+        self._qcache = {}
+
+    def _apply(self, fn, *a, **k):
+        self._qcache = {}
+        return super()._apply(fn, *a, **k)
+
+    def _quality_params(self, i, device):
+        if not self.apply_quality_in_inference:
+            return None
+        if self.reg_topk != 4 or not self.add_mean:
+            raise NotImplementedError("the decode kernel is built for reg_topk=4, add_mean=True (the reference defaults)")
+        q = self._qcache.get((i, device))
+        if q is None:
+            m = self.reg_conf[i]
+            f = lambda t: t.detach().float().to(device).contiguous()  # noqa: E731
+            q = self._qcache[(i, device)] = (f(m[0].weight).view(m[0].out_channels, -1), f(m[0].bias), f(m[2].weight).view(-1), f(m[2].bias))
+        return q
+
+
+class GFLHeadv2_uniH(GF2Detect):
+    """reference head.py:827-908.  stem/dat/pos/cit are nn.Identity placeholders there (use_* default False);
+    forward == GF2Detect.forward through the `super()` calls at :898,:907."""
+
+    def __init__(self, nc=80, ch=(), reg_topk=4, add_mean=True, reg_channels=64, use_dat=False, use_cit=False, use_poscnn=False):
+        super().__init__(nc, ch)
+        if use_dat or use_cit or use_poscnn:
+            raise NotImplementedError("use_dat/use_cit/use_poscnn only add nn.Identity placeholders in the reference; not built")
+        self.stem = nn.ModuleList(nn.Identity() for _ in ch)
+        self.dat = self.pos_cls = self.pos_reg = self.cit_cls = self.cit_reg = None
+        self.reg_topk = reg_topk
+        self.add_mean = add_mean
+        self.reg_channels = reg_channels
+        in_stat = 4 * (self.reg_topk + (1 if self.add_mean else 0))
+        self.reg_conf = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(in_stat, self.reg_channels, 1, bias=True), nn.ReLU(inplace=True), nn.Conv2d(self.reg_channels, 1, 1, bias=True),
+                          nn.Sigmoid()) for _ in ch)

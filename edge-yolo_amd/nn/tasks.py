@@ -1,0 +1,233 @@
+"""YAML -> model graph and the graph executor, mirroring the reference's ultralytics/nn/tasks.py for the detect
+path: `parse_model` (:958-1147), `yaml_model_load` (:1150-1163), `guess_model_scale` (:1166-1181),
+`guess_model_task` (:1184-1255), `BaseModel._predict_once/fuse` (:152-242), `DetectionModel` (:320-370).
+"""
+import ast
+import contextlib
+import re
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import _ops as ops
+from .modules import (C2PSA, C2PSA_LinearAttention, C2f, C3, C3k2, Concat, Conv, DSC3K2_Wavelet, DSConv, DWConv, Detect, GF2Detect,
+                      GFLHeadv2_uniH, SPPF, Upsample)
+from .modules import *  # noqa: F401,F403  (registry: YAML names resolve through globals(), as in the reference)
+from .modules.conv import _Packed
+from .. import _lib as L
+from ..utils.ops import make_divisible
+
+CFG_DIR = Path(__file__).resolve().parent.parent / "cfg" / "models"
+_CH_MODULES = {Conv, SPPF, C2PSA, C2PSA_LinearAttention, DWConv, C2f, C3k2, DSC3K2_Wavelet, C3, DSConv}
+_REPEAT_MODULES = {C2f, C3k2, DSC3K2_Wavelet, C3, C2PSA, C2PSA_LinearAttention}
+_HEADS = {Detect, GF2Detect, GFLHeadv2_uniH}
+
+
+def guess_model_scale(model_path):
+    """'yolo11n-test.yaml' -> 'n' (reference tasks.py:1166-1181)."""
+    try:
+        return re.search(r"yolo[v]?\d+([nslmx])", Path(model_path).stem).group(1)
+    except AttributeError:
+        return ""
+
+
+def yaml_model_load(path):
+    """Load a model YAML; 'yolo11n-test.yaml' resolves to the unified 'yolo11-test.yaml' + scale 'n' (tasks.py:1150-1163).
+    Bare file names are looked up under edge-yolo_amd/cfg/models/**."""
+    path = Path(path)
+    unified = Path(re.sub(r"(\d+)([nslmx])(.+)?$", r"\1\3", str(path)))
+    for cand in (unified, path):
+        for f in ([cand] if cand.exists() else sorted(CFG_DIR.rglob(cand.name))):
+            d = yaml.safe_load(open(f, encoding="utf-8"))
+            d["scale"] = guess_model_scale(path)
+            d["yaml_file"] = str(path)
+            return d
+    raise FileNotFoundError(f"model YAML '{path}' not found (also searched {CFG_DIR})")
+
+
+def guess_model_task(model):
+    """Reference tasks.py:1184-1255 reduced to this build's scope.  The reference only recognises heads whose
+    lower-cased name contains 'detect' and raises for GFLHeadv2_uniH YAMLs unless task='detect' is passed
+    (SURVEY §3 quirk); here every registered head is a detect head."""
+    cfg = model if isinstance(model, dict) else None
+    if cfg is None and isinstance(model, (str, Path)):
+        with contextlib.suppress(Exception):
+            cfg = yaml_model_load(model)
+    if cfg is not None:
+        m = cfg["head"][-1][-2]
+        if m in {h.__name__ for h in _HEADS}:
+            return "detect"
+        raise NotImplementedError(f"head '{m}': only the detect task is built")
+    return "detect"
+
+
+def parse_model(d, ch, verbose=False):
+    """YAML dict -> (nn.Sequential, savelist).  Channel/repeat rewriting as reference tasks.py:958-1147."""
+    legacy = True
+    max_channels = float("inf")
+    nc, act, scales = (d.get(x) for x in ("nc", "activation", "scales"))
+    depth, width = (d.get(x, 1.0) for x in ("depth_multiple", "width_multiple"))
+    scale = d.get("scale")
+    if scales:
+        if not scale:
+            scale = tuple(scales.keys())[0]
+        depth, width, max_channels = scales[scale]
+    if act:
+        Conv.default_act = eval(act)  # noqa: S307  (same YAML contract as the reference, tasks.py:974-975)
+    ch = [ch]
+    layers, save, c2 = [], [], ch[-1]
+    for i, (f, n, m, args) in enumerate(d["backbone"] + d["head"]):
+        args = list(args)
+        if m == "nn.Upsample":
+            m = Upsample
+        elif isinstance(m, str) and m.startswith("nn."):
+            raise NotImplementedError(f"torch module '{m}' is not on the built detection path")
+        else:
+            if m not in globals():
+                raise NotImplementedError(f"module '{m}' is not in the edge-yolo_amd registry (SURVEY.md §8a lists what is)")
+            m = globals()[m]
+        for j, a in enumerate(args):
+            if isinstance(a, str):
+                with contextlib.suppress(ValueError):
+                    args[j] = locals()[a] if a in locals() else ast.literal_eval(a)
+        n = n_ = max(round(n * depth), 1) if n > 1 else n
+        if m in _CH_MODULES:
+            c1, c2 = ch[f], args[0]
+            if c2 != nc:
+                c2 = make_divisible(min(c2, max_channels) * width, 8)
+            args = [c1, c2, *args[1:]]
+            if m in _REPEAT_MODULES:
+                args.insert(2, n)
+                n = 1
+            if m in {C3k2, DSC3K2_Wavelet}:
+                legacy = False
+                if scale in "lx":
+                    args[3] = True
+        elif m is Concat:
+            c2 = sum(ch[x] for x in f)
+        elif m in _HEADS:
+            args.append([ch[x] for x in f])
+            m.legacy = legacy
+        else:
+            c2 = ch[f]
+        m_ = nn.Sequential(*(m(*args) for _ in range(n))) if n > 1 else m(*args)
+        t = f"{m.__module__}.{m.__name__}".replace("edge_yolo_amd", "ultralytics") if m is not Upsample else "torch.nn.modules.upsampling.Upsample"
+        m_.np = sum(x.numel() for x in m_.parameters())
+        m_.i, m_.f, m_.type = i, f, t
+        save.extend(x % i for x in ([f] if isinstance(f, int) else f) if x != -1)
+        layers.append(m_)
+        if i == 0:
+            ch = []
+        ch.append(c2)
+    return nn.Sequential(*layers), sorted(save)
+
+
+class BaseModel(nn.Module):
+    """forward / predict / _predict_once / fuse of the reference BaseModel (tasks.py:113-317), inference only."""
+
+    def forward(self, x, *args, **kwargs):
+        if isinstance(x, dict):
+            raise NotImplementedError("training losses are outside the built path (inference forward only)")
+        return self.predict(x, *args, **kwargs)
+
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+        if profile or visualize or embed:
+            raise NotImplementedError("profile/visualize/embed hooks are not part of the built path")
+        return self._predict_once(x)  # augment=True falls back to single scale exactly as the reference does (:181-187)
+
+    def _predict_once(self, x, profile=False, visualize=False, embed=None):
+        y = []
+        for m in self.model:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x
+
+    def fuse(self, verbose=False):
+        """Fold every Conv/DWConv BatchNorm into its conv parameters (reference tasks.py:214-242).  DSConv keeps its
+        BatchNorm as a module, as in the reference; it is folded when the HIP weights are packed."""
+        if not self.is_fused():
+            for m in self.model.modules():
+                if isinstance(m, Conv) and hasattr(m, "bn"):
+                    m.fuse_bn()
+        return self
+
+    def is_fused(self, thresh=10):
+        bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+        return sum(isinstance(v, bn) for v in self.modules()) < thresh
+
+    def _apply(self, fn, *args, **kwargs):
+        self = super()._apply(fn, *args, **kwargs)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            m.stride = fn(m.stride)
+            m.anchors = fn(m.anchors)
+            m.strides = fn(m.strides)
+        return self
+
+    def load(self, weights, verbose=False):
+        """Load a flat state_dict (tensor-only file or dict); intersecting keys/shapes only, like reference :276-291."""
+        sd = weights["state_dict"] if isinstance(weights, dict) and "state_dict" in weights else weights
+        own = self.state_dict()
+        csd = {k: v for k, v in sd.items() if k in own and own[k].shape == v.shape}
+        self.load_state_dict(csd, strict=False)
+        return len(csd), len(own)
+
+
+class DetectionModel(BaseModel):
+    """Detection model built from a YAML (reference tasks.py:320-370)."""
+
+    def __init__(self, cfg="yolo11n.yaml", ch=3, nc=None, verbose=False):
+        super().__init__()
+        self.yaml = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
+        ch = self.yaml["ch"] = self.yaml.get("ch", ch)
+        if nc and nc != self.yaml["nc"]:
+            self.yaml["nc"] = nc
+        self.model, self.save = parse_model(deepcopy(self.yaml), ch=ch, verbose=verbose)
+        self.names = {i: f"{i}" for i in range(self.yaml["nc"])}
+        self.inplace = self.yaml.get("inplace", True)
+        self.end2end = getattr(self.model[-1], "end2end", False)
+        m = self.model[-1]
+        if isinstance(m, Detect):
+            # The reference measures strides with a 256x256 zero forward (tasks.py:352-364); the same numbers follow
+            # from the graph (product of conv strides / upsample factors on the path to each head input) without
+            # needing a device at construction time.
+            m.stride = torch.tensor(self._graph_strides(ch))
+            self.stride = m.stride
+        for mod in self.modules():  # initialize_weights (utils/torch_utils.py:410-420)
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.eps = 1e-3
+                mod.momentum = 0.03
+        self.eval()
+
+    def _graph_strides(self, ch):
+        down = []
+        for m in self.model:
+            f = m.f if isinstance(m.f, int) else m.f[0]
+            src = 1.0 if (m.i == 0) else (down[f] if f != -1 else down[-1])
+            if isinstance(m, Conv):
+                src *= m.conv.stride[0]
+            elif isinstance(m, Upsample):
+                src /= 2
+            if isinstance(m, Detect):
+                return [float(down[j]) for j in m.f]
+            down.append(src)
+        raise RuntimeError("no detect head")
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("edge-yolo_amd builds the inference forward path only")
+        return super().train(False)
+
+
+def torch_safe_load_state(path):
+    """Tensor-only checkpoint reader (never unpickles code): torch.load(weights_only=True) or safetensors."""
+    path = str(path)
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    return torch.load(path, map_location="cpu", weights_only=True)

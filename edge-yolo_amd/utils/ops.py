@@ -1,0 +1,83 @@
+"""Post-processing of the detection path, mirroring the reference's ultralytics/utils/ops.py:
+`make_divisible` (:130-143), `non_max_suppression` (:167-316), `xywh2xyxy` (:416-433), `scale_boxes` (:92-127),
+`clip_boxes` (:319-338).  NMS runs in the HIP library (ey_nms); there is no torch/torchvision fallback."""
+import math
+
+import torch
+
+
+def make_divisible(x, divisor):
+    if isinstance(divisor, torch.Tensor):
+        divisor = int(divisor.max())
+    return math.ceil(x / divisor) * divisor
+
+
+def xywh2xyxy(x):
+    assert x.shape[-1] == 4, f"input shape last dimension expected 4 but input shape is {x.shape}"
+    y = torch.empty_like(x)
+    xy, wh = x[..., :2], x[..., 2:] / 2
+    y[..., :2] = xy - wh
+    y[..., 2:] = xy + wh
+    return y
+
+
+def clip_boxes(boxes, shape):
+    boxes[..., 0] = boxes[..., 0].clamp(0, shape[1])
+    boxes[..., 1] = boxes[..., 1].clamp(0, shape[0])
+    boxes[..., 2] = boxes[..., 2].clamp(0, shape[1])
+    boxes[..., 3] = boxes[..., 3].clamp(0, shape[0])
+    return boxes
+
+
+def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xywh=False):
+    """Rescale xyxy boxes from the network input shape to the original image shape (reference :92-127)."""
+    if ratio_pad is None:
+        gain = min(img1_shape[0] / img0_shape[0], img1_shape[1] / img0_shape[1])
+        pad = (round((img1_shape[1] - img0_shape[1] * gain) / 2 - 0.1), round((img1_shape[0] - img0_shape[0] * gain) / 2 - 0.1))
+    else:
+        gain, pad = ratio_pad[0][0], ratio_pad[1]
+    if padding:
+        boxes[..., 0] -= pad[0]
+        boxes[..., 1] -= pad[1]
+        if not xywh:
+            boxes[..., 2] -= pad[0]
+            boxes[..., 3] -= pad[1]
+    boxes[..., :4] /= gain
+    return clip_boxes(boxes, img0_shape)
+
+
+def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, nc=0, max_nms=30000, max_wh=7680):
+    """Batched NMS on the device, fixed-size outputs (graph-capturable): returns (boxes (B,max_det,6), count (B,),
+    index (B,max_det)).  `prediction` is (B,4+nc,A); fp16 input is promoted to fp32 first (the reference promotes inside
+    NMS, ops.py:275; this build keeps head outputs in fp32 end to end)."""
+    from ..nn import _ops
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
+    assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    nc = nc or (prediction.shape[1] - 4)
+    if prediction.shape[1] - nc - 4:
+        raise NotImplementedError("mask/keypoint channels (nm>0) are outside the detect path")
+    p = prediction.float().contiguous()
+    mask = None
+    if classes is not None:
+        mask = torch.zeros(nc, dtype=torch.uint8)
+        mask[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+        mask = mask.to(p.device)
+    return _ops.nms(p, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, mask)
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
+                        max_det=300, nc=0, max_time_img=0.05, max_nms=30000, max_wh=7680, in_place=True, rotated=False):
+    """Reference signature (ops.py:167-183); returns a list of (n_i, 6) tensors [x1,y1,x2,y2,conf,cls].
+    Differences, all deliberate: no wall-clock abort (:238,:312-314 make the reference output timing dependent);
+    the input tensor is not rewritten to xyxy in place; multi_label / labels / rotated are not built and raise."""
+    if multi_label or (labels and len(labels)) or rotated:
+        raise NotImplementedError("multi_label / autolabel / rotated NMS variants are not part of the built predict path")
+    if isinstance(prediction, (list, tuple)):
+        prediction = prediction[0]
+    if prediction.shape[-1] == 6:
+        raise NotImplementedError("end-to-end (B,N,6) predictions need no NMS and are outside the built path")
+    boxes, count, _ = nms_device(prediction, conf_thres, iou_thres, classes, agnostic, max_det, nc, max_nms, max_wh)
+    n = count.tolist()  # one D2H sync for the whole batch
+    return [boxes[i, : n[i]] for i in range(len(n))]

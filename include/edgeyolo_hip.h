@@ -1,0 +1,156 @@
+/*
+ * edgeyolo_hip.h — C ABI of libedgeyolo_hip.so: the MI355X (gfx950) detection forward path of EdgeLine-YOLO.
+ *
+ * The reference (OneWalkman/EDGE-YOLO, an Ultralytics 8.3.63 fork) is pure Python/PyTorch and has NO FFI of its
+ * own; the operators below are the ATen / torchvision call sites of its predict() hot path.
+ * Each entry point names the reference function it replaces (paths relative to /root/reference/ultralytics/).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory unless it says "host";
+ *  - the caller owns all buffers; nothing is allocated, freed or synchronised inside; every launch goes to the
+ *    hipStream_t passed as `stream` (so the calls can be captured into a hipGraph);
+ *  - return 0 on success, a negative EY_E* code otherwise; ey_last_error() gives the message (thread local);
+ *  - activations are NHWC ("channels last"): element (b,y,x,c) of a view lives at
+ *        ptr + (((b*H + y)*W + x) * cstride + c)        [elements],
+ *    so a channel slice of a wider tensor is just (ptr + c0, cstride = C_total): chunk/split/cat never copy;
+ *  - dtype is the storage type of activations and packed weights (EY_F16 | EY_F32); accumulation, bias,
+ *    softmax, decode and NMS arithmetic are always fp32.  EY_F32 is the parity mode (exact-f32 MFMA),
+ *    EY_F16 the throughput mode.
+ */
+#ifndef EDGEYOLO_HIP_H
+#define EDGEYOLO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ey_stream_t; /* hipStream_t */
+
+enum { EY_F16 = 0, EY_F32 = 1 };
+enum { EY_ACT_NONE = 0, EY_ACT_SILU = 1, EY_ACT_RELU = 2, EY_ACT_SIGMOID = 3 };
+enum { EY_OK = 0, EY_EINVAL = -1, EY_EUNSUPPORTED = -2, EY_ELAUNCH = -3 };
+
+const char* ey_last_error(void);
+int ey_version(void);
+
+/* ---- K1: dense convolution (+ folded-BN bias, activation, residual) as NHWC implicit GEMM on MFMA ------------
+ * Replaces Conv.forward_fuse (nn/modules/conv.py:57-59, BN folded by utils/torch_utils.py:238-265), the raw
+ * nn.Conv2d+bias calls of the heads (nn/modules/head.py:61,70) and LinearAttention.qkv/proj (block.py:3357-3358);
+ * also absorbs nn.Upsample(nearest x2)+Concat feeding a conv (yaml layers 11-12,14-15,18,21; conv.py:353-355),
+ * Bottleneck/PSA residual adds (block.py:480,3446-3449) and the _WaveletEnhancer tail (block.py:3706-3710).
+ *
+ *   y = res + out_scale * act( conv_k(cat_c(src0, src1)) + bias + bilinear_up2x(addz) )
+ *
+ * src[i] may be read through a nearest x2^up upsample (src_up = 0|1).  k in {1,3}, stride in {1,2}, pad = k/2.
+ * `ngroup` > 1 runs the same weights over `ngroup` channel-offset slices (src0 += g*src_gstride,
+ * y += g*y_gstride elements) — the three high-frequency sub-bands share f_h (block.py:3691-3694).
+ * Weights must be packed by ey_conv_pack_weight(). */
+typedef struct {
+  int32_t dtype;
+  int32_t B, H, W;   /* logical conv input extent (after the virtual upsample) */
+  int32_t Ho, Wo;    /* output extent */
+  int32_t Cout;
+  int32_t k, stride, pad;
+  int32_t act;
+  int32_t nsrc;      /* 1 or 2 */
+  const void* src[2];
+  int32_t src_C[2];
+  int32_t src_cstride[2];
+  int32_t src_up[2];
+  const void* w;     /* packed, see ey_conv_pack_weight */
+  const float* bias; /* [Cout] fp32 or NULL */
+  void* y;
+  int32_t y_cstride;
+  const void* res;   /* optional, [B,Ho,Wo,Cout] view, same dtype */
+  int32_t res_cstride;
+  float out_scale;   /* 1.0f unless the wavelet tail (tanh(gamma)) */
+  const void* addz;  /* optional, [B,addz_H,addz_W,Cout] view, bilinearly resized (align_corners=False) to Ho x Wo */
+  int32_t addz_cstride;
+  int32_t addz_H, addz_W;
+  int32_t ngroup;
+  int64_t src_gstride, y_gstride;
+} ey_conv_desc;
+
+/* Bytes of the packed weight buffer for a conv with Cout x (k*k*Cin) (Cin = sum of src_C). */
+size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k);
+/* host -> host: w_oihw fp32 [Cout][Cin][k][k]  ->  packed rows [Cout_pad][k][k][Cin] (+ row permutation for the
+ * MFMA epilogue, + zero slack).  Upload `out` to the device afterwards. */
+int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const float* w_oihw_host, void* out_host, size_t out_bytes);
+int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream);
+
+/* ---- generic direct convolution (any Cin/Cout/groups/k/stride; scalar) — correctness path for shapes the MFMA
+ * kernel does not take (channel counts not multiples of 8, grouped convs).  Weights: fp32 OIHW on device. */
+typedef struct {
+  int32_t dtype;
+  int32_t B, H, W, Cin, Ho, Wo, Cout;
+  int32_t k, stride, pad, groups, act;
+  const void* x; int32_t x_cstride;
+  const float* w_oihw; const float* bias;
+  void* y; int32_t y_cstride;
+} ey_conv_direct_desc;
+int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream);
+
+/* ---- stem: 3x3 stride-2 conv on the NCHW input image -> NHWC, + bias + SiLU (layer 0; conv.py:41-59).
+ * x: [B,Cin,H,W] contiguous, x_dtype EY_F16|EY_F32; w: fp32 [Cout][Cin][3][3] device; Cin<=4, Cout%16==0. */
+int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cout, int act, const void* x_nchw,
+                 const float* w_oihw, const float* bias, void* y, int y_cstride, ey_stream_t stream);
+
+/* ---- K2/K3: depthwise kxk, stride 1, pad k/2 (+ optional bias + activation).  DSConv.dw (conv.py:94-97,102) and
+ * DWConv (conv.py:124-129) in Detect.cv3 (head.py:68-69).  w: [k][k][C] in `dtype`; k in {3,5,7}; C%8==0. */
+int ey_dwconv(int dtype, int B, int H, int W, int C, int k, int act, const void* x, int x_cstride, const void* w_kkc,
+              const float* bias, void* y, int y_cstride, ey_stream_t stream);
+
+/* ---- K4: single-level 2-D Haar analysis (_PywtDWT2D.forward, block.py:3619-3642).
+ * x [B,H,W,C] -> y [B,H/2,W/2,4C] with channel blocks LL|LH|HL|HH; odd H/W floor like the stride-2 conv. */
+int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y, int y_cstride,
+                ey_stream_t stream);
+
+/* ---- K6: the three chained 5x5/s1/p2 max-pools of SPPF (block.py:219-223): y1=mp(x), y2=mp(y1), y3=mp(y2). */
+int ey_sppf_pool(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y1, void* y2, void* y3,
+                 int y_cstride, ey_stream_t stream);
+
+/* ---- K7 (module-level form): channel-slice copy with optional nearest x2 upsample — nn.Upsample / Concat
+ * (conv.py:345-355) when they are not folded into the consuming conv.  dst[b,y,x,c] = src[b,y>>up,x>>up,c]. */
+int ey_copy_nhwc(int dtype, int B, int H, int W, int C, int up, const void* src, int src_cstride, void* dst,
+                 int dst_cstride, ey_stream_t stream);
+/* NCHW-contiguous <-> NHWC view transposes (boundary with callers that hand over plain contiguous tensors). */
+int ey_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const void* src, void* dst, int dst_cstride, ey_stream_t stream);
+int ey_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* src, int src_cstride, void* dst, ey_stream_t stream);
+
+/* ---- K8a: linear attention core (LinearAttention.forward, block.py:3360-3373) between the qkv and proj convs.
+ * qkv [B,N,3C] channel order [q(h0..)|k|v] (block.py:3364); y [B,N,C]:  k=softmax_d(k); q=softmax_N(q);
+ * ctx_h = k_h^T v_h; y_h = q_h ctx_h.  head_dim = C/heads <= 64. */
+int ey_linear_attention(int dtype, int B, int N, int C, int heads, const void* qkv, int qkv_cstride, void* y,
+                        int y_cstride, ey_stream_t stream);
+
+/* ---- K8b: softmax attention core (Attention.forward, block.py:1042-1053) of the YOLO11 baseline PSA block.
+ * qkv [B,N,heads*(2*kd+hd)] per-head channel order [q(kd)|k(kd)|v(hd)]; y [B,N,heads*hd] = v @ softmax(q^T k * scale)^T. */
+int ey_softmax_attention(int dtype, int B, int N, int heads, int kd, int hd, float scale, const void* qkv,
+                         int qkv_cstride, void* y, int y_cstride, ey_stream_t stream);
+
+/* ---- K9+K10: DGQP quality + DFL expectation + anchor decode + score modulation for ONE pyramid level.
+ * Detect._inference (head.py:117-148), DFL (block.py:87-90), make_anchors/dist2bbox (utils/tal.py:333-357),
+ * GF2Detect._compute_quality_from_logits / _inference_with_quality (head.py:227-243,301-345).
+ * box [B,H,W,4*16], cls [B,H,W,nc]; q_* = reg_conf weights (fp32, device) or NULL for plain Detect:
+ *   q_w1 [64][20], q_b1 [64], q_w2 [64], q_b2 [1].
+ * pred fp32 [B, 4+nc, A_total]; this level fills anchors [a_off, a_off + H*W). */
+int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const void* box, int box_cstride,
+                   const void* cls, int cls_cstride, const float* q_w1, const float* q_b1, const float* q_w2,
+                   const float* q_b2, int q_hidden, float* pred, int A_total, int a_off, ey_stream_t stream);
+
+/* ---- K11: batched per-image NMS (non_max_suppression single-label path, utils/ops.py:230-316, and the
+ * torchvision.ops.nms it calls at :296).  pred fp32 [B,4+nc,A] (xywh + scores), NOT modified.
+ * out_boxes fp32 [B,max_det,6] = x1,y1,x2,y2,conf,cls in kept (descending score) order; out_count int32 [B];
+ * out_index int32 [B,max_det] = anchor index of each kept row (may be NULL); class_mask uint8 [nc] or NULL
+ * (the `classes=` filter).  workspace: ey_nms_workspace_bytes(B, A) bytes. */
+size_t ey_nms_workspace_bytes(int B, int A);
+int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms,
+           float max_wh, int agnostic, const uint8_t* class_mask, float* out_boxes, int32_t* out_count,
+           int32_t* out_index, void* workspace, size_t workspace_bytes, ey_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

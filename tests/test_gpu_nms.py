@@ -1,0 +1,79 @@
+"""-m gpu: ey_nms (through utils.ops.non_max_suppression) vs the reference-produced goldens and the CPU oracle.
+Kept rows and anchor indices must be BIT-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nms as onms, synth  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd.utils import ops
+    return ops
+
+
+def _preds(g):
+    return {
+        "sparse": synth.synth_pred(2, 80, 8400, seed=2), "dense": synth.synth_pred(1, 80, 8400, seed=3, dense=True),
+        "nc10": synth.synth_pred(1, 10, 336, seed=5, imgsz=128, dense=True),
+        "none_pass": synth.synth_pred(2, 80, 336, seed=6) * torch.tensor(1e-3), "hand": torch.tensor(g["hand_pred"]),
+    }
+
+
+def test_golden_cases(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "nms_cases.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "nms_cases.json")))
+    preds = _preds(g)
+    for tag, m in meta.items():
+        if m["kw"].get("multi_label"):
+            continue  # val-mode NMS is a SURVEY §8(f) "next" row; the entry point raises NotImplementedError for it
+        base = "sparse" if tag.startswith("sparse") else "hand" if tag.startswith("hand") else tag
+        out = ops.non_max_suppression(preds[base].cuda(), **m["kw"])
+        assert [int(o.shape[0]) for o in out] == m["n"], tag
+        for i, o in enumerate(out):
+            np.testing.assert_array_equal(o.cpu().numpy(), g[f"{tag}_{i}"], err_msg=tag)
+
+
+@pytest.mark.parametrize("B,nc,A,dense,conf,iou,max_det", [(4, 80, 8400, False, 0.25, 0.7, 300), (2, 80, 8400, True, 0.25, 0.45, 300),
+                                                         (3, 3, 1000, True, 0.1, 0.5, 50), (1, 80, 33600, False, 0.25, 0.7, 300),
+                                                         (2, 1, 64, True, 0.3, 0.6, 10), (2, 80, 20000, True, 0.5, 0.7, 100)])
+def test_vs_oracle_indices(ops, B, nc, A, dense, conf, iou, max_det):
+    pred = synth.synth_pred(B, nc, A, seed=11, dense=dense)
+    want, widx = onms.non_max_suppression(pred.numpy(), conf, iou, max_det=max_det, return_idx=True)
+    boxes, count, index = ops.nms_device(pred.cuda(), conf, iou, max_det=max_det)
+    count = count.cpu().numpy()
+    for b in range(B):
+        n = int(count[b])
+        assert n == want[b].shape[0]
+        np.testing.assert_array_equal(index[b, :n].cpu().numpy(), widx[b])  # indices bit-exact
+        np.testing.assert_array_equal(boxes[b, :n].cpu().numpy(), want[b])  # rows bit-exact
+        assert float(boxes[b, n:].abs().sum()) == 0.0
+
+
+def test_score_ties_and_pow2_edge(ops):
+    """All scores equal: order must be ascending anchor index (stable sort); A exactly a power of two."""
+    A = 256
+    pred = torch.zeros(1, 4 + 2, A)
+    pred[0, 0] = torch.arange(A) * 50.0 + 25  # disjoint boxes
+    pred[0, 1] = 25.0
+    pred[0, 2:4] = 20.0
+    pred[0, 4] = 0.5
+    out = ops.non_max_suppression(pred.cuda(), 0.25, 0.5, max_det=300)[0].cpu()
+    want = onms.non_max_suppression(pred.numpy(), 0.25, 0.5, max_det=300)[0]
+    np.testing.assert_array_equal(out.numpy(), want)
+    assert out.shape[0] == A
+
+
+def test_argument_errors(ops):
+    pred = synth.synth_pred(1, 4, 64, seed=1).cuda()
+    with pytest.raises(AssertionError):
+        ops.non_max_suppression(pred, conf_thres=1.5)
+    with pytest.raises(NotImplementedError):
+        ops.non_max_suppression(pred, multi_label=True)

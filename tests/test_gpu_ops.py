@@ -1,0 +1,186 @@
+"""-m gpu: every HIP operator against the CPU oracle on seeded inputs (through the Python modules, i.e. through the
+C ABI).  fp32 = parity gate, fp16 = throughput mode (tolerances: tests/gpu_util.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om, synth  # noqa: E402
+from gpu_util import check, load_synth, to_dev  # noqa: E402
+
+DT = [torch.float32, torch.float16]
+
+
+def _x(b, c, h, w, dtype, seed=0):
+    x = synth.synth_images(b, h, w, seed=seed, c=c) - 0.5
+    return x, x.to("cuda", dtype)
+
+
+@pytest.fixture(scope="module")
+def M():
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd.nn import modules
+    return modules
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c1,c2,k,s,h,w", [
+    (16, 8, 1, 1, 12, 10), (16, 8, 3, 1, 12, 10), (32, 32, 1, 1, 16, 16), (48, 64, 1, 1, 20, 12), (16, 32, 3, 2, 32, 32),
+    (64, 64, 3, 2, 16, 16), (64, 80, 1, 1, 9, 7), (80, 80, 1, 1, 9, 7), (96, 128, 1, 1, 8, 8), (128, 128, 3, 2, 14, 10),
+    (128, 256, 3, 2, 8, 8), (192, 64, 1, 1, 5, 5), (256, 64, 3, 1, 6, 6), (384, 256, 1, 1, 4, 4), (128, 384, 1, 1, 4, 4),
+    (512, 256, 1, 1, 3, 3), (64, 32, 3, 1, 13, 9), (24, 40, 3, 1, 7, 7), (64, 12, 1, 1, 6, 5)])
+def test_conv(M, dtype, c1, c2, k, s, h, w):
+    m = M.Conv(c1, c2, k, s)
+    sd = load_synth(m, "cv")
+    x, xd = _x(3, c1, h, w, dtype)
+    want = om.conv(sd, "cv", x, k, s)
+    check(to_dev(m, dtype)(xd), want, dtype, what=f"Conv {c1}->{c2} k{k}s{s}")
+    m.fuse_bn()  # fused parameters must give the same result (BaseModel.fuse)
+    check(m(xd), want, dtype, what="fused")
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_views_residual(M, dtype):
+    """out= into a channel slice of a wider buffer, input from a channel slice, residual add."""
+    from edge_yolo_amd import _lib as L
+    m = M.Conv(32, 32, 3, 1)
+    sd = load_synth(m, "cvr")
+    x, xd = _x(2, 64, 10, 12, dtype)
+    m = to_dev(m, dtype)
+    buf = L.empty_nhwc(2, 96, 10, 12, dtype, "cuda")
+    buf.zero_()
+    xin = L.as_nhwc(xd)[:, 32:]
+    m(xin, out=buf[:, 32:64], res=xin)
+    want = x[:, 32:] + om.conv(sd, "cvr", x[:, 32:], 3, 1)
+    check(buf[:, 32:64], want, dtype)
+    assert float(buf[:, :32].abs().max()) == 0 and float(buf[:, 64:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("h,w", [(64, 64), (34, 50)])
+def test_stem(M, dtype, h, w):
+    m = M.Conv(3, 16, 3, 2)
+    sd = load_synth(m, "stem")
+    x = synth.synth_images(2, h, w)
+    got = to_dev(m, dtype)(x.to("cuda", dtype))
+    check(got, om.conv(sd, "stem", x, 3, 2), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("k", [3, 5, 7])
+def test_dsconv(M, dtype, k):
+    m = M.DSConv(16, 24, k)
+    sd = load_synth(m, "ds")
+    x, xd = _x(2, 16, 9, 11, dtype)
+    check(to_dev(m, dtype)(xd), om.dsconv(sd, "ds", x, k), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dwconv(M, dtype):
+    m = M.DWConv(80, 80, 3)
+    sd = load_synth(m, "dw")
+    x, xd = _x(2, 80, 7, 9, dtype)
+    check(to_dev(m, dtype)(xd), om.dwconv(sd, "dw", x, 3), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_direct_fallback(M, dtype):
+    """channel counts the MFMA kernel does not take go through the generic direct kernel."""
+    m = M.Conv(20, 12, 3, 1)
+    sd = load_synth(m, "cd")
+    x, xd = _x(2, 20, 6, 7, dtype)
+    check(to_dev(m, dtype)(xd), om.conv(sd, "cd", x, 3, 1), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_dwt(M, dtype):
+    from edge_yolo_amd.nn.modules.block import _PywtDWT2D
+    x, xd = _x(2, 16, 10, 14, dtype)
+    got = _PywtDWT2D()(xd)
+    for g, w in zip(got, om.haar_dwt(x)):
+        check(g, w, dtype)
+    q = torch.tensor([[[[1., 2.], [3., 4.]]]]).repeat(1, 8, 1, 1).to("cuda", dtype)
+    ll, lh, hl, hh = _PywtDWT2D()(q)
+    assert [round(float(t[0, 0, 0, 0])) for t in (ll, lh, hl, hh)] == [5, -1, -2, 0]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("h,w", [(10, 14), (9, 13), (3, 5)])
+def test_wavelet_enhancer(M, dtype, h, w):
+    """even maps (exact x2 upsample) and odd maps (DWT floors, bilinear resize by a non-integer ratio)."""
+    from edge_yolo_amd.nn.modules.block import _WaveletEnhancer
+    m = _WaveletEnhancer(16)
+    sd = load_synth(m, "enh")
+    x, xd = _x(2, 16, h, w, dtype)
+    check(to_dev(m, dtype)(xd), om.wavelet_enhancer(sd, "enh", x), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c1,c2,dsc3k,e", [(32, 64, False, 0.25), (128, 128, True, 0.5), (384, 128, False, 0.5)])
+def test_dsc3k2_wavelet(M, dtype, c1, c2, dsc3k, e):
+    m = M.DSC3K2_Wavelet(c1, c2, 1, dsc3k, e)
+    sd = load_synth(m, "blk")
+    x, xd = _x(2, c1, 12, 8, dtype)
+    check(to_dev(m, dtype)(xd), om.dsc3k2_wavelet(sd, "blk", x, 1, dsc3k), dtype, scale=2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c3k", [False, True])
+def test_c3k2(M, dtype, c3k):
+    m = M.C3k2(64, 128, 1, c3k, 0.5)
+    sd = load_synth(m, "c3k2")
+    x, xd = _x(2, 64, 9, 9, dtype)
+    check(to_dev(m, dtype)(xd), om.c3k2(sd, "c3k2", x, 1, c3k), dtype, scale=2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("h,w", [(7, 9), (20, 20)])
+def test_sppf(M, dtype, h, w):
+    m = M.SPPF(64, 96, 5)
+    sd = load_synth(m, "sppf")
+    x, xd = _x(2, 64, h, w, dtype)
+    check(to_dev(m, dtype)(xd), om.sppf(sd, "sppf", x), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("linear", [True, False])
+@pytest.mark.parametrize("h,w", [(4, 4), (20, 20)])
+def test_c2psa(M, dtype, linear, h, w):
+    m = (M.C2PSA_LinearAttention if linear else M.C2PSA)(256, 256, 1)
+    sd = load_synth(m, "psa")
+    x, xd = _x(2, 256, h, w, dtype)
+    check(to_dev(m, dtype)(xd), om.c2psa(sd, "psa", x, 1, linear), dtype, scale=2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_upsample_concat(M, dtype):
+    x, xd = _x(2, 32, 5, 6, dtype)
+    y, yd = _x(2, 16, 10, 12, dtype, seed=1)
+    up = M.Upsample(None, 2, "nearest")(xd)
+    check(up, torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"), dtype)
+    cat = M.Concat(1)([up, yd])
+    check(cat, torch.cat([torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"), y], 1), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("head,nc", [("GFLHeadv2_uniH", 80), ("Detect", 80), ("GFLHeadv2_uniH", 10)])
+def test_head(M, dtype, head, nc):
+    ch = (64, 128, 256)
+    m = getattr(M, head)(nc, ch)
+    m.stride = torch.tensor([8., 16., 32.])
+    sd = load_synth(m, "model.23")
+    xs = [synth.synth_images(2, h, w, seed=i, c=c) - 0.5 for i, (c, (h, w)) in enumerate(zip(ch, [(8, 12), (4, 6), (2, 3)]))]
+    want, raw = om.detect_head(sd, "model.23", [t.clone() for t in xs], nc, [8., 16., 32.], head != "Detect")
+    got, graw = to_dev(m, dtype)([t.to("cuda", dtype) for t in xs])
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(want.shape)
+    check(got[:, :4], want[:, :4], dtype, scale=40 if dtype == torch.float16 else 5, what="boxes")
+    check(got[:, 4:], want[:, 4:], dtype, what="scores")
+    for a, b in zip(graw, raw):
+        check(a, b, dtype, what="raw")
+
+
+def test_no_cpu_fallback(M):
+    from edge_yolo_amd._lib import HipLibraryError
+    m = M.Conv(16, 16, 1)
+    with pytest.raises(HipLibraryError):
+        m.eval()(torch.zeros(1, 16, 4, 4))
