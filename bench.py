@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of the EdgeLine-YOLO detection forward path (stem -> backbone -> DWT neck ->
+GFLv2 head decode -> batched NMS) at 640x640, fp16 storage, synthetic images already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model yolo11n-test.yaml] [--batch 32] [--imgsz 640]
+
+N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; one process per GPU,
+images sharded across ranks (weak scaling: 32 images per GPU), one RCCL all_gather of the padded (B,300,6) result
+rows + counts per step on a side stream.  Rank 0 prints ONE JSON line.
+
+A "step" = one batch through the whole device path, replayed from a captured hipGraph: nothing is skipped (NMS and,
+for N>1, the gather are inside the timed region).  `roofline` = the dominant kernel of the step measured live with HIP
+events on the launch stream in an instrumented eager pass of the same steps; `cpu_baseline` = the CPU oracle
+(oracle/, a port of the reference's torch-CPU path, test infrastructure) timed on this box's host cores, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--model", default="yolo11n-test.yaml")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=16)
+    return ap.parse_args()
+
+
+def build_model(name, dtype, device, seed=0):
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd.nn.tasks import DetectionModel
+    from oracle import synth  # synthetic weight generator only (name-keyed, shared with the tests)
+    m = DetectionModel(name)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
+    m.load_state_dict(sd)
+    m = m.to(device).fuse()
+    m = m.half() if dtype == torch.float16 else m.float()
+    return m.eval(), sd
+
+
+def cpu_baseline(name, sd, imgsz, n_images, conf, iou):
+    """The CPU port of the reference path (oracle/) on this box's host cores: forward + NMS, fp32."""
+    from oracle import model as om, nms as onms
+    ncpu = os.cpu_count() or 1
+    threads = max(1, min(8, ncpu - 1))  # the reference's select_device rule (utils/torch_utils.py:225-226)
+    torch.set_num_threads(threads)
+    o = om.OracleModel(os.path.join(ROOT, "edge-yolo_amd", "cfg", "models", "11", name), {k: v.float() for k, v in sd.items()})
+    g = torch.Generator().manual_seed(0)
+    bs = min(8, n_images)
+    x = torch.rand(bs, 3, imgsz, imgsz, generator=g)
+    o(x[:1])  # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while done < n_images:
+        y, _ = o(x)
+        onms.non_max_suppression(y.numpy(), conf, iou)
+        done += bs
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{done} images {imgsz}x{imgsz} fp32, batch {bs}, forward+NMS, oracle/ (torch-CPU port of the reference path), {threads} threads"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.float16 if a.dtype == "f16" else torch.float32
+    conf, iou, max_det = 0.25, 0.7, 300
+
+    from edge_yolo_amd.engine.predictor import GraphRunner
+    from edge_yolo_amd.utils import ops
+    from edge_yolo_amd import dist as eydist
+    model, sd = build_model(a.model, dtype, dev)
+
+    g = torch.Generator(device=dev).manual_seed(rank)
+    images = torch.rand(a.batch, 3, a.imgsz, a.imgsz, generator=g, device=dev).to(dtype)  # resident in HBM before timing
+
+    def device_step(im):
+        pred, _ = model(im)
+        boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
+        return boxes, count
+
+    runner = GraphRunner(device_step)
+    gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if world > 1 else None
+
+    def step():
+        boxes, count = runner(images)
+        if gather is not None:
+            gather(boxes, count)
+        return boxes, count
+
+    for _ in range(a.warmup):
+        step()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        boxes, count = step()
+    if gather is not None:
+        gather.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        total_images = a.batch * world * a.steps
+        out = {
+            "metric": "images/sec @ 640x640 fp16 (EdgeLine-YOLO detection forward path: backbone + DWT neck + GFLv2 head decode + batched NMS)",
+            "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{a.model} (EdgeLine-YOLO scale n, nc=80) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
+                                   f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
+                                   f"{float(count.float().mean()):.0f})",
+                       "global_batch": a.batch * world, "imgsz": a.imgsz, "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
+        }
+    if rank == 0 and not a.no_roofline:
+        from edge_yolo_amd import profiling
+        out["roofline"] = profiling.dominant_kernel_roofline(lambda: device_step(images), steps=min(a.steps, 10), hbm_peak_gbs=HBM_PEAK_GBS,
+                                                             mfma_peak_tflops=MFMA_F16_PEAK_TFLOPS)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

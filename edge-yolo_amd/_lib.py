@@ -44,9 +44,11 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "ey_last_error": (C.c_char_p, []),
     "ey_version": (_i, []),
+    "ey_abi_sizeof": (_sz, [_i]),
     "ey_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ey_conv_pack_weight": (_i, [_i, _i, _i, _i, _vp, _vp, _sz]),
     "ey_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
+    "ey_conv_tile": (_i, [_i, C.c_long, _i]),
     "ey_conv2d_direct": (_i, [C.POINTER(ConvDirectDesc), _vp]),
     "ey_stem_conv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ey_dwconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
@@ -79,6 +81,8 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        if L.ey_abi_sizeof(0) != C.sizeof(ConvDesc) or L.ey_abi_sizeof(1) != C.sizeof(ConvDirectDesc):
+            raise HipLibraryError(f"{LIB_PATH}: struct layout differs from this binding (stale build?): rebuild with make -C csrc")
         _lib = L
     return _lib
 

@@ -15,3 +15,4 @@ int ey_set_error(int code, const char* fmt, ...) {
 
 extern "C" const char* ey_last_error(void) { return g_err; }
 extern "C" int ey_version(void) { return 1; }
+extern "C" size_t ey_abi_sizeof(int which) { return which == 0 ? sizeof(ey_conv_desc) : which == 1 ? sizeof(ey_conv_direct_desc) : 0; }

@@ -223,6 +223,13 @@ extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const fl
   return EY_OK;
 }
 
+// which instantiation ey_conv2d picks: returns NT*16 + MT (profiling / documentation only)
+extern "C" int ey_conv_tile(int Cout, long M, int ngroup) {
+  const int NT = conv_nt(Cout), ntiles = (Cout + 16 * NT - 1) / (16 * NT);
+  const long blocks2 = (M + 127) / 128 * ntiles * (ngroup > 0 ? ngroup : 1);
+  return NT * 16 + (blocks2 >= 512 ? 2 : 1);
+}
+
 template <typename T, int NT>
 static void launch_conv(const ConvP& p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;

@@ -6,6 +6,28 @@ import torch
 
 from .. import _lib as L
 
+TRACE = None  # set by edge-yolo_amd/profiling.py: per-launch HIP-event timing + algorithmic bytes/FLOPs
+
+
+class _NoTrace:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NT = _NoTrace()
+
+
+def _tr(kernel, nbytes, flops=0):
+    return TRACE.launch(kernel, nbytes, flops) if TRACE is not None else _NT
+
+
+def _nb(*tensors):
+    """algorithmic bytes: every listed tensor view touched exactly once."""
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
 
 def _dev_key(x, tag=""):
     return (tag, x.dtype, x.device)
@@ -90,6 +112,14 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
             raise ValueError("conv2d: addz batch/channel/dtype mismatch")
         d.addz, d.addz_cstride, d.addz_H, d.addz_W = addz.data_ptr(), L.cstride(addz), addz.shape[2], addz.shape[3]
     d.ngroup, d.src_gstride, d.y_gstride = ngroup, src_gstride, y_gstride
+    if TRACE is not None:
+        M = B * Ho * Wo
+        es = x0.element_size()
+        tile = L.lib().ey_conv_tile(cout, M, ngroup)
+        nbytes = ngroup * (_nb(*srcs) + M * cout * es * (2 if res is not None else 1) + _nb(addz)) + cout * cin * k * k * es
+        with _tr(f"conv_igemm_kernel<{'f16' if es == 2 else 'f32'},{tile >> 4},{tile & 15}>", nbytes, 2.0 * ngroup * M * cout * cin * k * k):
+            L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
+        return out
     L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
     return out
 
@@ -118,7 +148,8 @@ def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""
     d.w_oihw = w.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     d.y, d.y_cstride = out.data_ptr(), L.cstride(out)
-    L.check(L.lib().ey_conv2d_direct(ctypes.byref(d), L.stream()), "ey_conv2d_direct")
+    with _tr("conv_direct_kernel", _nb(x, out), 2.0 * B * Ho * Wo * cout * (cin // g) * k * k):
+        L.check(L.lib().ey_conv2d_direct(ctypes.byref(d), L.stream()), "ey_conv2d_direct")
     return out
 
 
@@ -136,8 +167,9 @@ def stem_conv(mod, x, folded_fn, act, out_dtype, out=None):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     if out is None:
         out = L.empty_nhwc(B, cout, Ho, Wo, out_dtype, x.device)
-    L.check(L.lib().ey_stem_conv(L.dtype_code(x.dtype), L.dtype_code(out_dtype), B, cin, H, W, cout, act, x.data_ptr(), w.data_ptr(),
-                                 bias.data_ptr(), out.data_ptr(), L.cstride(out), L.stream()), "ey_stem_conv")
+    with _tr("stem_kernel", _nb(x, out), 2.0 * B * Ho * Wo * cout * cin * 9):
+        L.check(L.lib().ey_stem_conv(L.dtype_code(x.dtype), L.dtype_code(out_dtype), B, cin, H, W, cout, act, x.data_ptr(), w.data_ptr(),
+                                     bias.data_ptr(), out.data_ptr(), L.cstride(out), L.stream()), "ey_stem_conv")
     return out
 
 
@@ -157,8 +189,9 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     wk, bias = mod._packed(_dev_key(x, "dw" + tag), build)
     if out is None:
         out = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
-    L.check(L.lib().ey_dwconv(L.dtype_code(x.dtype), B, H, W, c, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
-                              bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out), L.stream()), "ey_dwconv")
+    with _tr(f"dwconv_kernel<{k}>", _nb(x, out), 2.0 * x.numel() * k * k):
+        L.check(L.lib().ey_dwconv(L.dtype_code(x.dtype), B, H, W, c, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out), L.stream()), "ey_dwconv")
     return out
 
 
@@ -169,7 +202,8 @@ def dwt_haar(x, out=None):
     B, c, H, W = x.shape
     if out is None:
         out = L.empty_nhwc(B, 4 * c, H // 2, W // 2, x.dtype, x.device)
-    L.check(L.lib().ey_dwt_haar(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), out.data_ptr(), L.cstride(out), L.stream()), "ey_dwt_haar")
+    with _tr("dwt_kernel", _nb(x, out), 4.0 * x.numel()):
+        L.check(L.lib().ey_dwt_haar(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), out.data_ptr(), L.cstride(out), L.stream()), "ey_dwt_haar")
     return out
 
 
@@ -179,15 +213,17 @@ def sppf_pool(x, y1, y2, y3):
     cs = L.cstride(y1)
     if L.cstride(y2) != cs or L.cstride(y3) != cs:
         raise ValueError("sppf_pool: outputs must share one pixel stride")
-    L.check(L.lib().ey_sppf_pool(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), cs,
-                                 L.stream()), "ey_sppf_pool")
+    with _tr("sppf_kernel", _nb(x, y1, y2, y3)):
+        L.check(L.lib().ey_sppf_pool(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), cs,
+                                     L.stream()), "ey_sppf_pool")
 
 
 def copy_slice(src, dst, up=0):
     """dst[b,c,y,x] = src[b,c,y>>up,x>>up] (both NHWC views)."""
     B, c, H, W = dst.shape
-    L.check(L.lib().ey_copy_nhwc(L.dtype_code(dst.dtype), B, H, W, c, up, src.data_ptr(), L.cstride(src), dst.data_ptr(), L.cstride(dst), L.stream()),
-            "ey_copy_nhwc")
+    with _tr("copy_kernel", _nb(src, dst)):
+        L.check(L.lib().ey_copy_nhwc(L.dtype_code(dst.dtype), B, H, W, c, up, src.data_ptr(), L.cstride(src), dst.data_ptr(), L.cstride(dst), L.stream()),
+                "ey_copy_nhwc")
     return dst
 
 
@@ -229,8 +265,9 @@ def linear_attention(qkv, heads, out=None):
     c = c3 // 3
     if out is None:
         out = L.empty_nhwc(B, c, H, W, qkv.dtype, qkv.device)
-    L.check(L.lib().ey_linear_attention(L.dtype_code(qkv.dtype), B, H * W, c, heads, qkv.data_ptr(), L.cstride(qkv), out.data_ptr(), L.cstride(out),
-                                        L.stream()), "ey_linear_attention")
+    with _tr("linattn_kernel", _nb(qkv, out), 4.0 * B * H * W * c * (c // heads)):
+        L.check(L.lib().ey_linear_attention(L.dtype_code(qkv.dtype), B, H * W, c, heads, qkv.data_ptr(), L.cstride(qkv), out.data_ptr(), L.cstride(out),
+                                            L.stream()), "ey_linear_attention")
     return out
 
 
@@ -240,8 +277,9 @@ def softmax_attention(qkv, heads, kd, hd, scale, out=None):
     B, _, H, W = qkv.shape
     if out is None:
         out = L.empty_nhwc(B, heads * hd, H, W, qkv.dtype, qkv.device)
-    L.check(L.lib().ey_softmax_attention(L.dtype_code(qkv.dtype), B, H * W, heads, kd, hd, float(scale), qkv.data_ptr(), L.cstride(qkv),
-                                         out.data_ptr(), L.cstride(out), L.stream()), "ey_softmax_attention")
+    with _tr("softattn_kernel", _nb(qkv, out), 2.0 * B * heads * (H * W) ** 2 * (kd + hd)):
+        L.check(L.lib().ey_softmax_attention(L.dtype_code(qkv.dtype), B, H * W, heads, kd, hd, float(scale), qkv.data_ptr(), L.cstride(qkv),
+                                             out.data_ptr(), L.cstride(out), L.stream()), "ey_softmax_attention")
     return out
 
 
@@ -252,8 +290,9 @@ def head_decode(box, cls, stride, q, pred, a_off):
     nc = cls.shape[1]
     qa = [t.data_ptr() for t in q] if q is not None else [None] * 4
     hid = q[0].shape[0] if q is not None else 0
-    L.check(L.lib().ey_head_decode(L.dtype_code(box.dtype), B, H, W, nc, float(stride), box.data_ptr(), L.cstride(box), cls.data_ptr(), L.cstride(cls),
-                                   qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
+    with _tr("head_decode_kernel", _nb(box, cls) + B * H * W * (4 + nc) * 4, 2.0 * B * H * W * (hid * 21 + 200)):
+        L.check(L.lib().ey_head_decode(L.dtype_code(box.dtype), B, H, W, nc, float(stride), box.data_ptr(), L.cstride(box), cls.data_ptr(), L.cstride(cls),
+                                       qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
 
 
 def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None):
@@ -268,7 +307,8 @@ def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_m
     index = torch.empty((B, max_det), dtype=torch.int32, device=dev)
     nbytes = L.lib().ey_nms_workspace_bytes(B, A)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)),
-                           class_mask.data_ptr() if class_mask is not None else None, boxes.data_ptr(), count.data_ptr(), index.data_ptr(),
-                           ws.data_ptr(), nbytes, L.stream()), "ey_nms")
+    with _tr("nms(score+sort_greedy)", _nb(pred, boxes)):
+        L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)),
+                               class_mask.data_ptr() if class_mask is not None else None, boxes.data_ptr(), count.data_ptr(), index.data_ptr(),
+                               ws.data_ptr(), nbytes, L.stream()), "ey_nms")
     return boxes, count, index

@@ -1,0 +1,80 @@
+"""Per-launch timing of the HIP kernels with HIP events on the launch stream, plus the algorithmic bytes / FLOPs of
+each launch (what the op must move/compute if every tensor is touched exactly once): the inputs of bench.py's
+`roofline` object.  Tracing is off unless `trace()` is active; the product path never pays for it."""
+import contextlib
+
+import torch
+
+from .nn import _ops
+
+
+class Trace:
+    def __init__(self):
+        self.records = []  # (kernel, alg_bytes, alg_flops, start_event, end_event)
+
+    def launch(self, kernel, alg_bytes, alg_flops):
+        return _Launch(self, kernel, alg_bytes, alg_flops)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for k, b, f, s, e in self.records:
+            a = agg.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["bytes"] += b
+            a["flops"] += f
+        return agg
+
+
+class _Launch:
+    def __init__(self, tr, kernel, b, f):
+        self.tr, self.kernel, self.b, self.f = tr, kernel, b, f
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.e = torch.cuda.Event(enable_timing=True)
+        self.s.record()  # torch's current stream == the stream the kernel is launched on (_lib.stream())
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e))
+
+
+@contextlib.contextmanager
+def trace():
+    t = Trace()
+    _ops.TRACE = t
+    try:
+        yield t
+    finally:
+        _ops.TRACE = None
+
+
+def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
+    step_fn()
+    torch.cuda.synchronize()
+    with trace() as t:
+        for _ in range(steps):
+            step_fn()
+    agg = t.summary()
+    total = sum(a["ms"] for a in agg.values())
+    name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    avg_us = a["ms"] * 1e3 / a["launches"]
+    bytes_per = a["bytes"] / a["launches"]
+    flops_per = a["flops"] / a["launches"]
+    balance = mfma_peak_tflops * 1e12 / (hbm_peak_gbs * 1e9)
+    out = {"kernel": name, "launches_per_step": a["launches"] // steps, "avg_launch_us": round(avg_us, 3),
+           "share_of_traced_device_time": round(a["ms"] / total, 4)}
+    if flops_per / max(bytes_per, 1.0) >= balance:
+        ach = flops_per / (avg_us * 1e-6) / 1e12
+        out.update({"bound": "mfma", "achieved": round(ach, 3), "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": round(ach / mfma_peak_tflops, 4)})
+    else:
+        ach = bytes_per / (avg_us * 1e-6) / 1e9
+        out.update({"bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(ach / hbm_peak_gbs, 4)})
+    out["alg_bytes_per_launch"] = int(bytes_per)
+    out["alg_flops_per_launch"] = int(flops_per)
+    out["traffic"] = None  # HBM bytes from PMC counters: collected offline (profiles/), see DESIGN.md
+    out["top5"] = [{"kernel": k, "ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps}
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:5]]
+    return out

@@ -34,6 +34,8 @@ enum { EY_OK = 0, EY_EINVAL = -1, EY_EUNSUPPORTED = -2, EY_ELAUNCH = -3 };
 
 const char* ey_last_error(void);
 int ey_version(void);
+/* sizeof(ey_conv_desc) (which=0) / sizeof(ey_conv_direct_desc) (which=1) as compiled: lets a binding check its struct layout. */
+size_t ey_abi_sizeof(int which);
 
 /* ---- K1: dense convolution (+ folded-BN bias, activation, residual) as NHWC implicit GEMM on MFMA ------------
  * Replaces Conv.forward_fuse (nn/modules/conv.py:57-59, BN folded by utils/torch_utils.py:238-265), the raw
@@ -79,6 +81,8 @@ size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k);
  * MFMA epilogue, + zero slack).  Upload `out` to the device afterwards. */
 int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const float* w_oihw_host, void* out_host, size_t out_bytes);
 int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream);
+/* Tile variant ey_conv2d picks for (Cout, M = B*Ho*Wo, ngroup): NT*16 + MT (block tile = 64*MT pixels x 16*NT channels). */
+int ey_conv_tile(int Cout, long M, int ngroup);
 
 /* ---- generic direct convolution (any Cin/Cout/groups/k/stride; scalar) — correctness path for shapes the MFMA
  * kernel does not take (channel counts not multiples of 8, grouped convs).  Weights: fp32 OIHW on device. */

@@ -1,0 +1,152 @@
+"""CPU-only tests of the host side: C-ABI library loads and exports every declared symbol, YAML registry / graph
+builder parity with the reference (structure goldens), BN folding and weight packing, view plumbing, loud failure
+without a GPU.  No kernel is launched here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import edge_yolo_amd  # noqa: F401
+from edge_yolo_amd import _lib as L
+from edge_yolo_amd.nn import modules as M
+from edge_yolo_amd.nn.tasks import DetectionModel, guess_model_scale, guess_model_task, yaml_model_load
+from edge_yolo_amd.utils import ops as uops
+from oracle import model as om, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "edgeyolo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ey_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/edgeyolo_hip.h but not exported"
+    assert declared == set(L.SIGNATURES), "ctypes binding table and header disagree"
+    assert L.lib().ey_version() >= 1
+    # struct layouts must match the header (sizes as the C compiler lays them out)
+    assert L.lib().ey_abi_sizeof(0) == ctypes.sizeof(L.ConvDesc) and L.lib().ey_abi_sizeof(1) == ctypes.sizeof(L.ConvDirectDesc)
+
+
+@pytest.fixture(scope="module")
+def structure(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "structure.json")))
+
+
+@pytest.mark.parametrize("name", ["yolo11n.yaml", "yolo11s.yaml", "yolo11l.yaml", "yolo11n-test.yaml", "yolo11s-test.yaml", "yolo11l-test.yaml",
+                                  "yolo11n-tune.yaml", "yolo11n-lineattention.yaml", "yolo11n-DSC3K2_Wavelet.yaml", "yolo11n-GF2Detect.yaml"])
+def test_registry_builds_the_reference_graph(structure, name):
+    g = structure[name]
+    m = DetectionModel(name)
+    assert sum(p.numel() for p in m.parameters()) == g["params"]
+    assert m.save == g["save"] and [float(s) for s in m.stride] == g["stride"]
+    assert [l.type for l in m.model] == [l["type"] for l in g["layers"]]
+    assert [int(l.np) for l in m.model] == [l["np"] for l in g["layers"]]
+    assert [l.f for l in m.model] == [l["f"] for l in g["layers"]]
+    assert len(m.state_dict()) == g["nkeys"]
+    if "state_shapes" in g:
+        assert {k: list(v.shape) for k, v in m.state_dict().items()} == g["state_shapes"]
+
+
+def test_nc_override_and_scale_guess(structure):
+    m = DetectionModel("yolo11n-test.yaml", nc=10)
+    assert sum(p.numel() for p in m.parameters()) == structure["yolo11n-test.yaml@nc10"]["params"]
+    sd = m.state_dict()
+    for k, s in structure["yolo11n-test.yaml@nc10"]["state_shapes"].items():
+        assert list(sd[k].shape) == s
+    assert guess_model_scale("yolo11x-test.yaml") == "x" and guess_model_scale("foo.yaml") == ""
+    assert yaml_model_load("yolo11s-tune.yaml")["scale"] == "s"
+    assert guess_model_task("yolo11n-test.yaml") == "detect"  # the reference raises unless task= is passed
+    assert [uops.make_divisible(v, 8) for v in (16.0, 17.0, 256.0, 150.0)] == [16, 24, 256, 152]
+    with pytest.raises(FileNotFoundError):
+        yaml_model_load("yolo99q.yaml")
+
+
+def test_fuse_matches_reference_fold(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ops_small.npz"))
+    c = M.Conv(16, 24, 3, 2)
+    c.load_state_dict({k: synth.synth_tensor("conv_s2." + k, tuple(v.shape)) for k, v in c.state_dict().items()})
+    c.bn.eps = 1e-3
+    w, b = c.folded()
+    np.testing.assert_allclose(w.numpy(), g["conv_s2_fused_w"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(b.numpy(), g["conv_s2_fused_b"], rtol=1e-5, atol=1e-6)
+    c.fuse_bn()
+    assert not hasattr(c, "bn") and set(c.state_dict()) == {"conv.weight", "conv.bias"}
+    np.testing.assert_allclose(c.conv.weight.detach().numpy(), g["conv_s2_fused_w"], rtol=1e-5, atol=1e-6)
+    m = DetectionModel("yolo11n-test.yaml")
+    n_bn = sum(isinstance(x, torch.nn.BatchNorm2d) for x in m.modules())
+    m.fuse()
+    left = sum(isinstance(x, torch.nn.BatchNorm2d) for x in m.modules())
+    assert left == 22 and n_bn > left  # DSConv BatchNorms survive fuse(), as in the reference
+
+
+@pytest.mark.parametrize("cout,cin,k", [(8, 16, 3), (64, 48, 1), (80, 64, 1), (256, 128, 3), (12, 24, 1)])
+def test_weight_packing_layout(cout, cin, k):
+    """packed[row][ (ky*k+kx)*Cin + c ] with the documented row permutation; pad rows/slack are zero."""
+    w = torch.randn(cout, cin, k, k)
+    nbytes = L.lib().ey_conv_packed_bytes(L.F32, cout, cin, k)
+    buf = torch.zeros(nbytes, dtype=torch.uint8)
+    assert L.lib().ey_conv_pack_weight(L.F32, cout, cin, k, w.data_ptr(), buf.data_ptr(), nbytes) == 0
+    kp = k * k * cin + 32
+    p = buf.view(torch.float32).view(-1, kp)
+    nt = (L.lib().ey_conv_tile(cout, 1 << 20, 1)) >> 4
+    bn = 16 * nt
+    seen = set()
+    for row in range(p.shape[0]):
+        nb, within = divmod(row, bn)
+        t, rho = divmod(within, 16)
+        gq, j = divmod(rho, 4)
+        ch = nb * bn + gq * 4 * nt + 4 * t + j
+        if ch < cout:
+            seen.add(ch)
+            want = w[ch].permute(1, 2, 0).reshape(-1)  # (ky,kx,c)
+            assert torch.equal(p[row, : k * k * cin], want)
+        else:
+            assert float(p[row].abs().sum()) == 0
+        assert float(p[row, k * k * cin:].abs().sum()) == 0
+    assert seen == set(range(cout))
+    assert L.lib().ey_conv_pack_weight(L.F32, cout, cin, 5, w.data_ptr(), buf.data_ptr(), nbytes) != 0
+    assert b"k=5" in L.lib().ey_last_error()
+
+
+def test_nhwc_view_plumbing():
+    x = L.empty_nhwc(2, 48, 5, 7, torch.float16, "cpu")
+    assert L.is_nhwc_view(x) and L.cstride(x) == 48 and x.is_contiguous(memory_format=torch.channels_last)
+    s = x[:, 16:32]
+    assert L.is_nhwc_view(s) and L.cstride(s) == 48 and s.data_ptr() == x.data_ptr() + 32
+    assert not L.is_nhwc_view(torch.zeros(2, 48, 5, 7))
+    assert L.is_nhwc_view(torch.zeros(2, 48, 5, 7).contiguous(memory_format=torch.channels_last))
+    assert L.dtype_code(torch.float16) == 0 and L.dtype_code(torch.float32) == 1
+    with pytest.raises(TypeError):
+        L.dtype_code(torch.bfloat16)
+
+
+def test_no_cpu_fallback_anywhere():
+    """The product path must fail loudly, not fall back, when there is no GPU / the tensor is on the CPU."""
+    m = DetectionModel("yolo11n-test.yaml")
+    with pytest.raises(L.HipLibraryError):
+        m(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(L.HipLibraryError):
+        uops.non_max_suppression(torch.zeros(1, 84, 100))
+    model = edge_yolo_amd.YOLO("yolo11n-test.yaml")
+    with pytest.raises(RuntimeError):
+        model.predict(torch.zeros(1, 3, 64, 64), device="cpu")
+    with pytest.raises(NotImplementedError):
+        m.train()
+    with pytest.raises(NotImplementedError):
+        uops.non_max_suppression(torch.zeros(1, 84, 100), multi_label=True)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "edge-yolo_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
