@@ -99,11 +99,10 @@ extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stri
 //   conf > thr (and the class filter) get the 64-bit key  (score_bits << 32) | (0xFFFFFFFF - anchor); others 0.
 //   Sorting keys DESCENDING = scores descending with ties broken by ascending candidate (= anchor) order, i.e. the
 //   stable descending sort torchvision.ops.nms applies to the compacted candidate list (ops.py:253,275,296).
-// Stage 2 (nms_sort_greedy): one workgroup per image: bitonic sort of the keys (LDS when <= 16384 keys, else in
-//   the global workspace), then greedy suppression by ONE wave: 64 sorted candidates at a time are tested against
-//   the kept list (LDS) and then resolved inside the wave with ballots.  Stops at max_det kept or at the first
-//   zero key.  IoU arithmetic is the torchvision CPU kernel's, op by op, with explicit round-to-nearest intrinsics
-//   (no FMA contraction) so that decisions are bit-identical with the fp32 CPU oracle.
+// Stage 2 (nms_select_greedy_kernel, below): per image, radix-select the next chunk of best candidates, sort only that
+//   chunk in LDS, run the greedy suppression on it with all 16 waves; repeat until max_det boxes are kept.
+//   IoU arithmetic is the torchvision CPU kernel's, op by op, with explicit round-to-nearest intrinsics (no FMA
+//   contraction), so decisions are bit-identical with the fp32 CPU oracle.
 __global__ __launch_bounds__(256) void nms_score_kernel(int nc, int A, const float* __restrict__ pred, float conf_thres,
                                                         const uint8_t* __restrict__ class_mask, unsigned long long* __restrict__ keys, int* __restrict__ cls_id, int P) {
   const int b = blockIdx.y;
@@ -127,94 +126,230 @@ __global__ __launch_bounds__(256) void nms_score_kernel(int nc, int A, const flo
 
 struct KeptBox { float x1, y1, x2, y2, area; };
 
+// torchvision CPU kernel arithmetic, op by op, round-to-nearest, no FMA contraction.  The early-out is exact: with
+// w<=0 or h<=0 the reference computes inter=0 and 0/union (0, -0 or NaN), none of which exceeds thr in [0,1].
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float aarea, float bx1, float by1, float bx2, float by2,
                                        float barea, float thr) {
-  const float xx1 = fmaxf(ax1, bx1), yy1 = fmaxf(ay1, by1), xx2 = fminf(ax2, bx2), yy2 = fminf(ay2, by2);
-  const float w = fmaxf(0.f, __fsub_rn(xx2, xx1)), h = fmaxf(0.f, __fsub_rn(yy2, yy1));
+  const float w = __fsub_rn(fminf(ax2, bx2), fmaxf(ax1, bx1));
+  const float h = __fsub_rn(fminf(ay2, by2), fmaxf(ay1, by1));
+  if (!(w > 0.f) || !(h > 0.f)) {
+    if (w != w || h != h) {  // NaN coordinates: fall through to the reference's full expression
+      const float ww = fmaxf(0.f, w), hh = fmaxf(0.f, h);
+      const float inter = __fmul_rn(ww, hh);
+      return __fdiv_rn(inter, __fsub_rn(__fadd_rn(aarea, barea), inter)) > thr;
+    }
+    return false;
+  }
   const float inter = __fmul_rn(w, h);
-  const float ovr = __fdiv_rn(inter, __fsub_rn(__fadd_rn(aarea, barea), inter));
-  return ovr > thr;
+  return __fdiv_rn(inter, __fsub_rn(__fadd_rn(aarea, barea), inter)) > thr;
 }
 
-template <bool LDS_SORT>
-__global__ __launch_bounds__(1024) void nms_sort_greedy_kernel(int nc, int A, int P, const float* __restrict__ pred, float iou_thres, int max_det,
-                                                               int max_nms, float max_wh, int agnostic, unsigned long long* __restrict__ gkeys,
-                                                               const int* __restrict__ cls_id, float* __restrict__ out_boxes, int* __restrict__ out_count, int* __restrict__ out_index) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x;
-  unsigned long long* keys = LDS_SORT ? reinterpret_cast<unsigned long long*>(smem) : gkeys + (long)b * P;
-  KeptBox* kept = reinterpret_cast<KeptBox*>(smem + (LDS_SORT ? (size_t)P * 8 : 0));
-  if (LDS_SORT) {
-    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = gkeys[(long)b * P + i];
-  }
+// Stage 2: one 1024-thread workgroup per image.
+//  (a) radix descent over the 64-bit keys from the top: a 4096-bin histogram of the current 12-bit digit picks the
+//      next CHUNK of >= ~1024 best remaining candidates (bins are taken whole, highest first); a bin holding more than
+//      NMS_CAP keys is opened on its next digit (keys are unique, so the descent terminates);
+//  (b) the chunk is gathered into LDS and bitonic-sorted (descending key = descending score, ties by ascending anchor);
+//  (c) greedy suppression over the sorted chunk, 1024 candidates at a time: every thread holds one candidate and
+//      first tests it against the kept list (parallel), then the 16 waves resolve their 64 candidates in order,
+//      each kept box being published to LDS and tested by all later candidates.
+//  Stops at max_det kept, max_nms candidates, or when the keys are exhausted.  Cost follows the number of
+//  candidates actually needed, not A: no full sort.
+#define NMS_CAP 4096
+#define NMS_TARGET 1024
+
+struct NmsShared {
+  unsigned hist[4096];
+  unsigned long long chunk[NMS_CAP];
+  int sel_lo, cnt, nkept, processed;
+};
+
+__device__ __forceinline__ void nms_block_suffix_scan(unsigned* h) {
+  // in place: h[b] <- sum_{b' >= b} h[b'] for 4096 bins, 1024 threads (4 bins each), Hillis-Steele over thread partials
+  __shared__ unsigned part[1024];
+  const int t = threadIdx.x;
+  unsigned v3 = h[4 * t + 3], v2 = h[4 * t + 2] + v3, v1 = h[4 * t + 1] + v2, v0 = h[4 * t] + v1;
+  part[t] = v0;
   __syncthreads();
-  // bitonic sort, descending
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        const int ixj = i ^ j;
-        if (ixj > i) {
-          const unsigned long long u = keys[i], v = keys[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (u < v) : (u > v)) { keys[i] = v; keys[ixj] = u; }
-        }
+  for (int off = 1; off < 1024; off <<= 1) {
+    unsigned add = (t + off < 1024) ? part[t + off] : 0u;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const unsigned above = (t + 1 < 1024) ? part[t + 1] : 0u;
+  h[4 * t] = v0 + above; h[4 * t + 1] = v1 + above; h[4 * t + 2] = v2 + above; h[4 * t + 3] = v3 + above;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, int P, const float* __restrict__ pred, float iou_thres, int max_det,
+                                                                 int max_nms, float max_wh, int agnostic,
+                                                                 const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
+                                                                 float* __restrict__ out_boxes, int* __restrict__ out_count,
+                                                                 int* __restrict__ out_index) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  NmsShared& S = *reinterpret_cast<NmsShared*>(smem);
+  KeptBox* kept = reinterpret_cast<KeptBox*>(smem + sizeof(NmsShared));
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long* keys = gkeys + (long)b * P;
+  const float* pb = pred + (long)b * (4 + nc) * A;
+  const int* cid = cls_id + (long)b * P;
+
+  // radix-descent state (wave-uniform, identical in every thread)
+  const int SHIFT[6] = {51, 39, 27, 15, 3, 0};
+  const int BITS[6] = {12, 12, 12, 12, 12, 3};
+  int level = 0, hi[6];
+  unsigned long long prefix[6];
+  hi[0] = 4096;
+  prefix[0] = 0ull;
+  if (tid == 0) { S.nkept = 0; S.processed = 0; }
+  bool need_hist = true;
+  __syncthreads();
+
+  while (true) {
+    if (S.nkept >= max_det || S.processed >= max_nms) break;
+    const int sh = SHIFT[level], nb = 1 << BITS[level];
+    const unsigned long long above_mask = level == 0 ? 0ull : (~0ull << SHIFT[level - 1]);
+    if (need_hist) {
+      for (int i = tid; i < 4096; i += 1024) S.hist[i] = 0u;
+      __syncthreads();
+      for (int i = tid; i < P; i += 1024) {
+        const unsigned long long k = keys[i];
+        if (k != 0ull && (k & above_mask) == prefix[level]) atomicAdd(&S.hist[(unsigned)(k >> sh) & (nb - 1)], 1u);
       }
       __syncthreads();
+      nms_block_suffix_scan(S.hist);  // hist[b] = #keys (under this prefix) with digit >= b
+      need_hist = false;
     }
-  }
-  if (threadIdx.x >= 64) return;  // greedy part: one wave (no further block barriers below)
-  const int lane = threadIdx.x;
-  const float* pb = pred + (long)b * (4 + nc) * A;
-  int nkept = 0;
-  const int limit = min(P, max_nms);
-  for (int base = 0; base < limit && nkept < max_det; base += 64) {
-    const int i = base + lane;
-    const unsigned long long key = i < limit ? keys[i] : 0ull;
-    bool alive = key != 0ull;
-    if (__ballot(alive) == 0ull) break;  // sorted: nothing but zeros from here on
-    float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f, conf = 0.f, ux1 = 0.f, uy1 = 0.f, ux2 = 0.f, uy2 = 0.f;
-    int a = 0, ci = 0;
-    if (alive) {
-      a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-      conf = __uint_as_float((unsigned)(key >> 32));
-      const float cx = pb[a], cy = pb[(long)A + a], w = pb[2L * A + a], h = pb[3L * A + a];
-      const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432 (x/2 is exact)
-      ux1 = __fsub_rn(cx, hw); uy1 = __fsub_rn(cy, hh); ux2 = __fadd_rn(cx, hw); uy2 = __fadd_rn(cy, hh);
-      ci = cls_id[(long)b * P + a];
-      const float off = agnostic ? 0.f : __fmul_rn((float)ci, max_wh);  // ops.py:289
-      x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
-      area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
-      for (int k = 0; k < nkept && alive; ++k) {
-        const KeptBox kb = kept[k];
-        if (iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, x1, y1, x2, y2, area, iou_thres)) alive = false;
+    const int H = hi[level];
+    const unsigned s_hi = H < 4096 ? S.hist[H] : 0u;  // keys already consumed at this level (digit >= H)
+    const unsigned remaining = S.hist[0] - s_hi;
+    if (H == 0 || remaining == 0u) {  // this subtree is exhausted
+      if (level == 0) break;
+      --level;
+      need_hist = true;
+      continue;
+    }
+    // lowest-cost chunk: the largest bin_lo < H whose digit range [bin_lo, H) holds >= NMS_TARGET keys (else 0)
+    if (tid == 0) S.sel_lo = 0;
+    __syncthreads();
+    for (int bin = tid; bin < H; bin += 1024)
+      if (S.hist[bin] - s_hi >= (unsigned)NMS_TARGET) atomicMax(&S.sel_lo, bin);
+    __syncthreads();
+    int lo = S.sel_lo;
+    unsigned cnt = S.hist[lo] - s_hi;
+    if (cnt > (unsigned)NMS_CAP) {
+      ++lo;  // drop the heavy lowest bin: what is left has < NMS_TARGET keys
+      cnt = lo < H ? S.hist[lo] - s_hi : 0u;
+      if (cnt == 0u) {  // the top remaining bin alone exceeds the cap: open it on its next digit
+        const int heavy = lo - 1;
+        hi[level] = heavy;  // when we come back, continue below it
+        prefix[level + 1] = prefix[level] | ((unsigned long long)heavy << sh);
+        ++level;
+        hi[level] = 1 << BITS[level];
+        need_hist = true;
+        __syncthreads();
+        continue;
       }
     }
-    // resolve inside the wave, in score order
-    for (int s = 0; s < 64; ++s) {
-      const unsigned long long am = __ballot(alive);
-      if (!((am >> s) & 1ull)) continue;
-      if (nkept >= max_det) break;
-      const float sx1 = __shfl(x1, s), sy1 = __shfl(y1, s), sx2 = __shfl(x2, s), sy2 = __shfl(y2, s), sarea = __shfl(area, s);
-      if (lane == s) {
-        kept[nkept] = KeptBox{x1, y1, x2, y2, area};
-        float* ob = out_boxes + ((long)b * max_det + nkept) * 6;
-        ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
-        if (out_index) out_index[(long)b * max_det + nkept] = a;
-      } else if (lane > s && alive) {
-        if (iou_gt(sx1, sy1, sx2, sy2, sarea, x1, y1, x2, y2, area, iou_thres)) alive = false;
+    hi[level] = lo;
+    // ---- gather the chunk (unordered), then sort it
+    if (tid == 0) S.cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < P; i += 1024) {
+      const unsigned long long k = keys[i];
+      if (k != 0ull && (k & above_mask) == prefix[level]) {
+        const int dgt = (int)((unsigned)(k >> sh) & (nb - 1));
+        if (dgt >= lo && dgt < H) S.chunk[atomicAdd(&S.cnt, 1)] = k;
       }
-      ++nkept;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    int n = (int)cnt;
+    int n2 = 64;
+    while (n2 < n) n2 <<= 1;
+    for (int i = n + tid; i < n2; i += 1024) S.chunk[i] = 0ull;
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (n2 >> 1); t += 1024) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+          const unsigned long long u = S.chunk[i], v = S.chunk[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (u < v) : (u > v)) { S.chunk[i] = v; S.chunk[ixj] = u; }
+        }
+        __syncthreads();
+      }
+    }
+    if (S.processed + n > max_nms) n = max_nms - S.processed;  // ops.py:285-286 cap
+    __syncthreads();
+    if (tid == 0) S.processed += n;
+
+    // ---- greedy suppression over the sorted chunk
+    for (int sb = 0; sb < n; sb += 1024) {
+      __syncthreads();
+      if (S.nkept >= max_det) break;
+      const int i = sb + tid;
+      bool alive = i < n;
+      float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f, conf = 0.f, ux1 = 0.f, uy1 = 0.f, ux2 = 0.f, uy2 = 0.f;
+      int a = 0, ci = 0;
+      if (alive) {
+        const unsigned long long key = S.chunk[i];
+        a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        conf = __uint_as_float((unsigned)(key >> 32));
+        const float cx = pb[a], cy = pb[(long)A + a], w = pb[2L * A + a], h = pb[3L * A + a];
+        const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432 (x/2 is exact)
+        ux1 = __fsub_rn(cx, hw); uy1 = __fsub_rn(cy, hh); ux2 = __fadd_rn(cx, hw); uy2 = __fadd_rn(cy, hh);
+        ci = cid[a];
+        const float off = agnostic ? 0.f : __fmul_rn((float)ci, max_wh);  // ops.py:289
+        x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
+        area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+      }
+      int checked = 0;
+      const int nwaves = min(16, (n - sb + 63) >> 6);
+      for (int w = 0; w < nwaves; ++w) {
+        __syncthreads();
+        const int nk = S.nkept;
+        if (nk >= max_det) break;
+        if (wave >= w) {  // catch up with boxes kept since this candidate was last tested
+          for (int k = checked; k < nk && alive; ++k) {
+            const KeptBox kb = kept[k];
+            if (iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, x1, y1, x2, y2, area, iou_thres)) alive = false;
+          }
+          checked = nk;
+        }
+        if (wave == w) {  // resolve this wave's 64 candidates in score order
+          int nkk = nk;
+          bool pending = alive;
+          while (nkk < max_det) {
+            const unsigned long long am = __ballot(pending);
+            if (am == 0ull) break;
+            const int s = __ffsll((unsigned long long)am) - 1;
+            const float sx1 = __shfl(x1, s), sy1 = __shfl(y1, s), sx2 = __shfl(x2, s), sy2 = __shfl(y2, s), sarea = __shfl(area, s);
+            if (lane == s) {
+              kept[nkk] = KeptBox{x1, y1, x2, y2, area};
+              float* ob = out_boxes + ((long)b * max_det + nkk) * 6;
+              ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
+              if (out_index) out_index[(long)b * max_det + nkk] = a;
+              pending = false;
+            } else if (pending && lane > s) {
+              if (iou_gt(sx1, sy1, sx2, sy2, sarea, x1, y1, x2, y2, area, iou_thres)) { pending = false; alive = false; }
+            }
+            ++nkk;
+          }
+          if (lane == 0) S.nkept = nkk;
+        }
+      }
+    }
+    __syncthreads();
   }
-  if (lane == 0) out_count[b] = nkept;
-  // zero the unused tail rows so the output is deterministic
-  for (int r = nkept * 6 + lane; r < max_det * 6; r += 64) out_boxes[(long)b * max_det * 6 + r] = 0.f;
+  __syncthreads();
+  const int nk = min(S.nkept, max_det);
+  if (tid == 0) out_count[b] = nk;
+  for (int r = nk * 6 + tid; r < max_det * 6; r += 1024) out_boxes[(long)b * max_det * 6 + r] = 0.f;
   if (out_index)
-    for (int r = nkept + lane; r < max_det; r += 64) out_index[(long)b * max_det + r] = -1;
+    for (int r = nk + tid; r < max_det; r += 1024) out_index[(long)b * max_det + r] = -1;
 }
 
-static int nms_pow2(int A) { int p = 64; while (p < A) p <<= 1; return p; }
+static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array length per image (padded for the score kernel grid)
 
 extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4); }  // keys + class ids
 
@@ -231,21 +366,15 @@ extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres,
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* keys = (unsigned long long*)workspace;
   int* cls_id = (int*)(keys + (size_t)B * P);
-  hipLaunchKernelGGL(nms_score_kernel, dim3(P / 64 >= 4 ? P / 256 : 1, B), dim3(P / 64 >= 4 ? 256 : P), 0, st, nc, A, pred, conf_thres, class_mask,
+  hipLaunchKernelGGL(nms_score_kernel, dim3(P / 256, B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask,
                      keys, cls_id, P);
   EY_LAUNCH_CHECK("ey_nms(score)");
-  const size_t kept_bytes = (size_t)max_det * sizeof(KeptBox);
-  if ((size_t)P * 8 + kept_bytes <= 160 * 1024) {
-    const size_t lds = (size_t)P * 8 + kept_bytes;
-    if (lds > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)nms_sort_greedy_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(nms_sort_greedy_kernel<true>, dim3(B), dim3(1024), lds, st, nc, A, P, pred, iou_thres, max_det, max_nms, max_wh, agnostic,
-                       keys, cls_id, out_boxes, out_count, out_index);
-  } else {
-    hipLaunchKernelGGL(nms_sort_greedy_kernel<false>, dim3(B), dim3(1024), kept_bytes, st, nc, A, P, pred, iou_thres, max_det, max_nms, max_wh, agnostic,
-                       keys, cls_id, out_boxes, out_count, out_index);
-  }
+  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox);
+  EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
+  if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
+  hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, pred, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id,
+                     out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }

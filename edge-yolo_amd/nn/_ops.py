@@ -20,8 +20,8 @@ class _NoTrace:
 _NT = _NoTrace()
 
 
-def _tr(kernel, nbytes, flops=0):
-    return TRACE.launch(kernel, nbytes, flops) if TRACE is not None else _NT
+def _tr(kernel, nbytes, flops=0, note=""):
+    return TRACE.launch(kernel, nbytes, flops, note) if TRACE is not None else _NT
 
 
 def _nb(*tensors):
@@ -117,7 +117,8 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         es = x0.element_size()
         tile = L.lib().ey_conv_tile(cout, M, ngroup)
         nbytes = ngroup * (_nb(*srcs) + M * cout * es * (2 if res is not None else 1) + _nb(addz)) + cout * cin * k * k * es
-        with _tr(f"conv_igemm_kernel<{'f16' if es == 2 else 'f32'},{tile >> 4},{tile & 15}>", nbytes, 2.0 * ngroup * M * cout * cin * k * k):
+        with _tr(f"conv_igemm_kernel<{'f16' if es == 2 else 'f32'},{tile >> 4},{tile & 15}>", nbytes, 2.0 * ngroup * M * cout * cin * k * k,
+                 note=f"{cin}->{cout} k{k}s{s} {H}x{W} g{ngroup}{' +res' if res is not None else ''}{' +addz' if addz is not None else ''}{' 2src' if len(srcs) > 1 else ''}"):
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
         return out
     L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
@@ -189,7 +190,7 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     wk, bias = mod._packed(_dev_key(x, "dw" + tag), build)
     if out is None:
         out = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
-    with _tr(f"dwconv_kernel<{k}>", _nb(x, out), 2.0 * x.numel() * k * k):
+    with _tr(f"dwconv_kernel<{k}>", _nb(x, out), 2.0 * x.numel() * k * k, note=f"C{c} {H}x{W}"):
         L.check(L.lib().ey_dwconv(L.dtype_code(x.dtype), B, H, W, c, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
                                   bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out), L.stream()), "ey_dwconv")
     return out

@@ -12,13 +12,13 @@ class Trace:
     def __init__(self):
         self.records = []  # (kernel, alg_bytes, alg_flops, start_event, end_event)
 
-    def launch(self, kernel, alg_bytes, alg_flops):
-        return _Launch(self, kernel, alg_bytes, alg_flops)
+    def launch(self, kernel, alg_bytes, alg_flops, note=""):
+        return _Launch(self, kernel, alg_bytes, alg_flops, note)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for k, b, f, s, e in self.records:
+        for k, b, f, s, e, _ in self.records:
             a = agg.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
             a["launches"] += 1
             a["ms"] += s.elapsed_time(e)
@@ -28,8 +28,8 @@ class Trace:
 
 
 class _Launch:
-    def __init__(self, tr, kernel, b, f):
-        self.tr, self.kernel, self.b, self.f = tr, kernel, b, f
+    def __init__(self, tr, kernel, b, f, note=""):
+        self.tr, self.kernel, self.b, self.f, self.note = tr, kernel, b, f, note
 
     def __enter__(self):
         self.s = torch.cuda.Event(enable_timing=True)
@@ -38,7 +38,7 @@ class _Launch:
 
     def __exit__(self, *a):
         self.e.record()
-        self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e))
+        self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e, self.note))
 
 
 @contextlib.contextmanager
