@@ -60,7 +60,31 @@ template <> struct Vec8<float> {
   __device__ __forceinline__ void set(int i, float x) { if (i < 4) lo[i] = x; else hi[i - 4] = x; }
 };
 
-__device__ __forceinline__ float ey_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+// 1/(1+e^-x) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (10+ instructions)
+__device__ __forceinline__ float ey_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+// ---- buffer loads with hardware range checking: an out-of-range byte offset returns zeros, so padding taps,
+// M tails and channel tails need no branches (offset EY_OOB is beyond any view: views are < 2 GiB, checked on the host)
+#define EY_OOB 0x80000000u
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ey_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <typename T> struct BufLoad8;
+template <> struct BufLoad8<f16> {
+  static __device__ __forceinline__ void load(Vec8<f16>& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    v.v = __builtin_bit_cast(f16x8, t);
+  }
+};
+template <> struct BufLoad8<float> {
+  static __device__ __forceinline__ void load(Vec8<float>& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, 0);
+    v.lo = __builtin_bit_cast(f32x4, a);
+    v.hi = __builtin_bit_cast(f32x4, b);
+  }
+};
 __device__ __forceinline__ float ey_act(float x, int act) {
   switch (act) {
     case EY_ACT_SILU: return x * ey_sigmoid(x);

@@ -10,8 +10,8 @@
 //   f32 : 8 x v_mfma_f32_16x16x4_f32 over the same 8-element fragments (exact f32 fma chain; parity mode)
 //
 // Workgroup = 4 waves; wave tile = (16*MT pixels) x (16*NT channels); block tile = 64*MT pixels x 16*NT channels.
-// Both operands are fragment-shaped global loads (weights are tiny and L1/L2 resident; every conv on this path
-// is HBM-bound on activations, which are read once because one block covers all of Cout up to 128).
+// Pixels are fragment-shaped global loads (each wave owns its pixels; activations are read once because one block
+// covers all of Cout up to 128); the weight tile shared by the 4 waves goes through LDS.
 #include "common.h"
 
 struct ConvP {
@@ -30,6 +30,12 @@ struct ConvP {
   float zsy, zsx;  // input/output size ratios of the bilinear resize
   long srcG, yG;
   int Kpad;      // packed row length (elements)
+  int nchunks;   // number of (tap, source, <=128-channel) K chunks
+  unsigned srcBytes[2];  // byte extent of each source view (buffer-load range check)
+  int Ctot, nsteps;      // total input channels; number of 32-channel K steps
+  int NTpack;    // NT the weights were packed with (row permutation), see ey_conv_pack_weight
+  int LSw;       // LDS row stride (elements) of the weight-stationary kernel
+  long ntile;    // number of wave tiles (16*MT pixels each)
   int vec_store; // 1: y/res/addz views are aligned for 4-element vector access
 };
 
@@ -44,13 +50,43 @@ __device__ __forceinline__ f32x4 mma16(const Vec8<float>& a, const Vec8<float>& 
   return c;
 }
 
+// K is walked in CHUNKS = (tap, source, <=128 channels).  Per chunk the block's weight tile [16*NT rows][chunk
+// channels] is staged into LDS (register-staged: global loads are issued before the MFMAs of the current chunk and
+// written to the other LDS buffer after them; padded rows -> conflict-free ds_read_b128), and every wave prefetches
+// its own pixel fragments of the next chunk into registers.  One barrier per chunk.
+#define CONV_CH 128           // channels per chunk
+#define CONV_LS (CONV_CH + 8)  // LDS row stride in elements (odd multiple of 16 B for f16)
+
+__device__ __forceinline__ void load4(const f16* p, float (&o)[4]) {
+  const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (float)v[j];
+}
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = v[j];
+}
+__device__ __forceinline__ void store4(f16* p, const float* v) {
+  const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, const float* v) {
+  const f32x4 o = {v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(p) = o;
+}
+
 template <typename T, int NT, int MT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* wlds = reinterpret_cast<T*>(smem);  // [2][16*NT][CONV_LS]
+  constexpr int BN = 16 * NT;
+  constexpr int WV = (BN * (CONV_CH / 8) + 255) / 256;  // 16-byte weight vectors staged per thread per chunk (max)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, g = lane >> 4;
   const long M = (long)p.B * p.Ho * p.Wo;
   const long m_wave0 = ((long)blockIdx.x * 4 + wave) * (16 * MT);
-  const int n_base = blockIdx.y * (16 * NT);
+  const int n_base = blockIdx.y * BN;
   const int grp = blockIdx.z;
 
   int pb[MT], poy[MT], pox[MT];
@@ -73,47 +109,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
 
-  const T* wrow[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) wrow[nt] = (const T*)p.w + (long)(n_base + nt * 16 + r) * p.Kpad + 8 * g;
+  const T* wg = (const T*)p.w + (long)n_base * p.Kpad;  // this block's rows of the packed weights
 
-  int kofs = 0;
-  for (int ky = 0; ky < p.k; ++ky) {
-    for (int kx = 0; kx < p.k; ++kx) {
-      int iy[MT], ix[MT];
-      bool inb[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        iy[mt] = poy[mt] * p.stride - p.pad + ky;
-        ix[mt] = pox[mt] * p.stride - p.pad + kx;
-        inb[mt] = pv[mt] && iy[mt] >= 0 && iy[mt] < p.H && ix[mt] >= 0 && ix[mt] < p.W;
+  // chunk iterator (wave-uniform)
+  int ky = 0, kx = 0, src = 0, c0 = 0, kofs = 0;
+  auto chunk_cc = [&]() { return min(CONV_CH, p.srcC[src] - c0); };
+  auto advance = [&]() {
+    const int cc = chunk_cc();
+    kofs += cc;
+    c0 += cc;
+    if (c0 >= p.srcC[src]) {
+      c0 = 0;
+      if (++src >= p.nsrc) {
+        src = 0;
+        if (++kx >= p.k) { kx = 0; ++ky; }
       }
-      for (int s = 0; s < p.nsrc; ++s) {
-        const int Cs = p.srcC[s], cs = p.srcCs[s], up = p.srcUp[s];
-        const int Hs = p.H >> up, Ws = p.W >> up;
-        const T* xb[MT];
+    }
+  };
+  // issue the global loads of one chunk: weight vectors -> wst, this wave's pixel fragments -> px
+  auto load_chunk = [&](Vec8<T> (&wst)[WV], Vec8<T> (&px)[MT][4]) {
+    const int cc = chunk_cc(), ksteps = (cc + 31) >> 5, vpr = ksteps * 4;  // 16-byte vectors per staged row
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          long pix = ((long)pb[mt] * Hs + (inb[mt] ? (iy[mt] >> up) : 0)) * Ws + (inb[mt] ? (ix[mt] >> up) : 0);
-          xb[mt] = (const T*)p.src[s] + (long)grp * p.srcG + pix * cs + 8 * g;
-        }
-        for (int c0 = 0; c0 < Cs; c0 += 32) {
-          const bool cvalid = (c0 + 8 * g) < Cs;
-          Vec8<T> bf[MT], af[NT];
+    for (int i = 0; i < WV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      const int row = v / vpr, c8 = (v - row * vpr) * 8;
+      if (row < BN && c8 < cc) wst[i].load(wg + (long)row * p.Kpad + kofs + c8);
+      else wst[i].zero();
+    }
+    const int cs = p.srcCs[src], up = p.srcUp[src];
+    const int Hs = p.H >> up, Ws = p.W >> up;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-            if (inb[mt] && cvalid) bf[mt].load(xb[mt] + c0);
-            else bf[mt].zero();
-          }
+    for (int mt = 0; mt < MT; ++mt) {
+      const int iy = poy[mt] * p.stride - p.pad + ky, ix = pox[mt] * p.stride - p.pad + kx;
+      const bool inb = pv[mt] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const long pix = ((long)pb[mt] * Hs + (inb ? (iy >> up) : 0)) * Ws + (inb ? (ix >> up) : 0);
+      const T* xb = (const T*)p.src[src] + (long)grp * p.srcG + pix * cs + c0 + 8 * g;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) af[nt].load(wrow[nt] + kofs + c0);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt], acc[mt][nt]);
-        }
-        kofs += Cs;
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < ksteps && inb && (ks * 32 + 8 * g) < cc) px[mt][ks].load(xb + ks * 32);
+        else px[mt][ks].zero();
       }
+    }
+    return ksteps;
+  };
+  auto store_w = [&](const Vec8<T> (&wst)[WV], int ksteps, T* buf) {
+    const int vpr = ksteps * 4;
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = threadIdx.x + i * 256;
+      const int row = v / vpr, c8 = (v - row * vpr) * 8;
+      if (row < BN) wst[i].store(buf + row * CONV_LS + c8);
+    }
+  };
+
+  Vec8<T> wst[WV], cur[MT][4], nxt[MT][4];
+  int ksteps = load_chunk(wst, cur);
+  store_w(wst, ksteps, wlds);
+  for (int ci = 0; ci < p.nchunks; ++ci) {
+    __syncthreads();  // buffer ci&1 is complete; nobody still reads buffer (ci+1)&1
+    const T* wb = wlds + (ci & 1) * (BN * CONV_LS);
+    int ksteps_next = 0;
+    const bool more = ci + 1 < p.nchunks;
+    if (more) {
+      advance();
+      ksteps_next = load_chunk(wst, nxt);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < ksteps) {
+        Vec8<T> af[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[nt].load(wb + (nt * 16 + r) * CONV_LS + ks * 32 + 8 * g);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], cur[mt][ks], acc[mt][nt]);
+      }
+    }
+    if (more) {
+      store_w(wst, ksteps_next, wlds + ((ci + 1) & 1) * (BN * CONV_LS));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) cur[mt][ks] = nxt[mt][ks];
+      ksteps = ksteps_next;
     }
   }
 
@@ -181,6 +260,200 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 }
 
+// ================================================================================================================
+// Weight-stationary persistent variant (the default): each 512-thread workgroup stages its whole weight tile
+// [16*NT rows][K] into LDS ONCE (zero-padded rows, odd 16-byte stride -> conflict-free ds_read_b128) and then its 8
+// waves walk the pixel tiles independently (no barrier after the staging): pixel fragments come straight from
+// global memory, up to 4 k-steps (128 channels) of loads in flight per wave, weights from LDS.  Weight traffic is
+// per workgroup instead of per 128 pixels, and there is no per-chunk synchronisation.
+template <typename T, int NT, int MT, int KS>
+__global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* wl = reinterpret_cast<T*>(smem);
+  constexpr int BN = 16 * NT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * BN;
+  const int grp = blockIdx.z;
+  {
+    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    const int kv = p.Kpad >> 3;
+    for (int v = threadIdx.x; v < BN * kv; v += 512) {
+      const int row = v / kv, c8 = (v - row * kv) << 3;
+      Vec8<T> w;
+      w.load(wg + (long)row * p.Kpad + c8);
+      w.store(wl + row * p.LSw + c8);
+    }
+  }
+  __syncthreads();
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int hw = p.Ho * p.Wo;
+  const T* wlane = wl + r * p.LSw + 8 * g;
+  // channel run owned by this lane in the epilogue (row permutation of ey_conv_pack_weight with NTpack)
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+
+  for (long tile = (long)wave * gridDim.x + blockIdx.x; tile < p.ntile; tile += (long)gridDim.x * 8) {
+    const long m0 = tile * (16 * MT);
+    int pb[MT], poy[MT], pox[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long m = m0 + mt * 16 + r;
+      pv[mt] = m < M;
+      const long mm = pv[mt] ? m : 0;
+      pb[mt] = (int)(mm / hw);
+      const int rem = (int)(mm - (long)pb[mt] * hw);
+      poy[mt] = rem / p.Wo;
+      pox[mt] = rem - poy[mt] * p.Wo;
+    }
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
+
+    // per-source lane byte offsets of the window origin (tap 0,0) and the descriptors
+    __amdgpu_buffer_rsrc_t rs[2];
+    int base[2][MT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s < p.nsrc) {
+        rs[s] = ey_rsrc((const T*)p.src[s] + (long)grp * p.srcG, p.srcBytes[s]);
+        const int up = p.srcUp[s], Hs = p.H >> up, Ws = p.W >> up;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int iy0 = poy[mt] * p.stride - p.pad, ix0 = pox[mt] * p.stride - p.pad;
+          // up==1 only occurs with k==1 (pad 0): the origin itself is the (only) tap
+          base[s][mt] = (((pb[mt] * Hs + (iy0 >> up)) * Ws + (ix0 >> up)) * p.srcCs[s] + 8 * g) * (int)sizeof(T);
+        }
+      }
+    }
+    int kofs = 0;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        bool inb[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int iy = poy[mt] * p.stride - p.pad + ky, ix = pox[mt] * p.stride - p.pad + kx;
+          inb[mt] = pv[mt] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (s < p.nsrc) {
+            const int Cs = p.srcC[s];
+            const int tapoff = (ky * p.W + kx) * p.srcCs[s] * (int)sizeof(T);  // (taps only exist when up == 0)
+            unsigned voff[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) voff[mt] = inb[mt] ? (unsigned)(base[s][mt] + tapoff) : EY_OOB;
+            for (int c0 = 0; c0 < Cs; c0 += 128) {
+              const int rem = Cs - c0;  // channels left in this source
+              Vec8<T> bf[MT][4];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                if (ks * 32 < rem) {
+                  const bool cok = (ks * 32 + 8 * g) < rem;
+#pragma unroll
+                  for (int mt = 0; mt < MT; ++mt)
+                    BufLoad8<T>::load(bf[mt][ks], rs[s], cok ? voff[mt] + (unsigned)((c0 + ks * 32) * (int)sizeof(T)) : EY_OOB);
+                }
+              }
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) {
+                if (ks * 32 < rem) {
+                  Vec8<T> af[NT];
+#pragma unroll
+                  for (int nt = 0; nt < NT; ++nt) af[nt].load(wlane + nt * 16 * p.LSw + kofs + c0 + ks * 32);
+#pragma unroll
+                  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt][ks], acc[mt][nt]);
+                }
+              }
+            }
+            kofs += Cs;
+          }
+        }
+      }
+    }
+
+    // ---- epilogue (same math as conv_igemm_kernel's)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!pv[mt]) continue;
+      const long m = m0 + mt * 16 + r;
+      float v[4 * NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j];
+      const bool full = ch0 + 4 * NT <= p.Cout;
+      if (p.bias) {
+        if (full) {
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] += bv[j];
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4 * NT; ++i)
+            if (ch0 + i < p.Cout) v[i] += p.bias[ch0 + i];
+        }
+      }
+      if (p.addz) {
+        const int Hz = p.Hz, Wz = p.Wz;
+        const float sy = fmaxf(p.zsy * (poy[mt] + 0.5f) - 0.5f, 0.f), sx = fmaxf(p.zsx * (pox[mt] + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
+        const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const T* z = (const T*)p.addz + (long)grp * p.yG;
+        const T* z00 = z + (((long)pb[mt] * Hz + y0) * Wz + x0) * p.addzCs + ch0;
+        const T* z01 = z + (((long)pb[mt] * Hz + y0) * Wz + x1) * p.addzCs + ch0;
+        const T* z10 = z + (((long)pb[mt] * Hz + y1) * Wz + x0) * p.addzCs + ch0;
+        const T* z11 = z + (((long)pb[mt] * Hz + y1) * Wz + x1) * p.addzCs + ch0;
+        if (p.vec_store && full) {
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            float a00[4], a01[4], a10[4], a11[4];
+            load4(z00 + 4 * q, a00); load4(z01 + 4 * q, a01); load4(z10 + 4 * q, a10); load4(z11 + 4 * q, a11);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4 * NT; ++i)
+            if (ch0 + i < p.Cout)
+              v[i] += ly0 * (lx0 * to_f(z00[i]) + lx1 * to_f(z01[i])) + ly1 * (lx0 * to_f(z10[i]) + lx1 * to_f(z11[i]));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+      T* yp = (T*)p.y + (long)grp * p.yG + m * p.yCs + ch0;
+      const T* rp = p.res ? (const T*)p.res + (long)grp * p.yG + m * p.resCs + ch0 : nullptr;
+      if (p.vec_store && full) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          if (rp) {
+            float rr[4];
+            load4(rp + 4 * q, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] += rr[j];
+          }
+          store4(yp + 4 * q, v + 4 * q);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i)
+          if (ch0 + i < p.Cout) yp[i] = from_f<T>(v[i] + (rp ? to_f(rp[i]) : 0.f));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int conv_nt(int Cout) {  // channels per block tile / 16
   if (Cout <= 16) return 1;
@@ -225,34 +498,130 @@ extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const fl
 
 // which instantiation ey_conv2d picks: returns NT*16 + MT (profiling / documentation only)
 extern "C" int ey_conv_tile(int Cout, long M, int ngroup) {
-  const int NT = conv_nt(Cout), ntiles = (Cout + 16 * NT - 1) / (16 * NT);
-  const long blocks2 = (M + 127) / 128 * ntiles * (ngroup > 0 ? ngroup : 1);
-  return NT * 16 + (blocks2 >= 512 ? 2 : 1);
+  (void)ngroup;
+  return conv_nt(Cout) * 16 + (M >= 65536 ? 2 : 1);  // packing NT; the kernel may use a divisor of it when LDS is short
+}
+
+template <typename T, int NT, int MT>
+static bool conv_lds_ok() {  // one-time opt-in to > 64 KiB of dynamic LDS for the big-tile / f32 variants
+  static const bool ok = [] {
+    const size_t lds = 2 * (size_t)(16 * NT) * CONV_LS * sizeof(T);
+    return lds <= 64 * 1024 ||
+           hipFuncSetAttribute((const void*)conv_igemm_kernel<T, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+  }();
+  return ok;
 }
 
 template <typename T, int NT>
-static void launch_conv(const ConvP& p, int ngroup, hipStream_t st) {
+static bool launch_conv(const ConvP& p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   const int ntiles = (p.Cout + 16 * NT - 1) / (16 * NT);
   const long blocks2 = (M + 127) / 128 * ntiles * ngroup;
+  const size_t lds = 2 * (size_t)(16 * NT) * CONV_LS * sizeof(T);
   if (blocks2 >= 512) {
+    if (!conv_lds_ok<T, NT, 2>()) return false;
     dim3 grid((unsigned)((M + 127) / 128), ntiles, ngroup);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, 2>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, 2>), grid, dim3(256), lds, st, p);
   } else {
+    if (!conv_lds_ok<T, NT, 1>()) return false;
     dim3 grid((unsigned)((M + 63) / 64), ntiles, ngroup);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, 1>), grid, dim3(256), 0, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, NT, 1>), grid, dim3(256), lds, st, p);
   }
+  return true;
+}
+
+// ---- weight-stationary dispatch
+static int ws_ls(int Kpad) { return ((Kpad >> 3) & 1) ? Kpad : Kpad + 8; }  // odd number of 16-byte (f16) units per row
+static const int WS_NT[5] = {8, 5, 4, 2, 1};
+// largest NT (<= the packing NT, dividing it into whole 16-row blocks) whose weight tile fits `budget` bytes of LDS
+static int ws_pick_nt(int Cout, int Kpad, int es, size_t budget) {
+  const int ntp = conv_nt(Cout);
+  for (int i = 0; i < 5; ++i) {
+    const int nt = WS_NT[i];
+    if (nt > ntp || ntp % nt) continue;
+    if ((size_t)16 * nt * ws_ls(Kpad) * es <= budget) return nt;
+  }
+  return 0;
+}
+
+template <typename T, int NT, int MT, int KS>
+static bool ws_launch(ConvP p, int ngroup, hipStream_t st) {
+  const size_t lds = (size_t)16 * NT * p.LSw * sizeof(T);
+  static size_t reserved = 0;
+  if (lds > 64 * 1024 && lds > reserved) {
+    if (hipFuncSetAttribute((const void*)conv_ws_kernel<T, NT, MT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    reserved = lds;
+  }
+  const long M = (long)p.B * p.Ho * p.Wo;
+  p.ntile = (M + 16 * MT - 1) / (16 * MT);
+  const int ntiles_n = (conv_cout_pad(p.Cout)) / (16 * NT);
+  const int wg_per_cu = lds > 76 * 1024 ? 1 : 2;
+  // persistent grid: one workgroup per resident slot; tiles are dealt round-robin over workgroups first, then waves,
+  // so a small layer still spreads over all CUs
+  long cap = (long)256 * wg_per_cu / ((long)ntiles_n * ngroup);
+  if (cap < 1) cap = 1;
+  long gx = p.ntile < cap ? p.ntile : cap;
+  dim3 grid((unsigned)gx, ntiles_n, ngroup);
+  hipLaunchKernelGGL((conv_ws_kernel<T, NT, MT, KS>), grid, dim3(512), lds, st, p);
+  return true;
+}
+
+template <typename T, int NT, int KS>
+static bool ws_launch_mt(const ConvP& p, int ngroup, hipStream_t st) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  // enough wave tiles to give every SIMD work: 2 pixel blocks per wave when M is large, else 1
+  if (M >= 65536) return ws_launch<T, NT, 2, KS>(p, ngroup, st);
+  return ws_launch<T, NT, 1, KS>(p, ngroup, st);
+}
+
+template <typename T, int KS>
+static bool ws_launch_nt(const ConvP& p, int nt, int ngroup, hipStream_t st) {
+  switch (nt) {
+    case 1: return ws_launch_mt<T, 1, KS>(p, ngroup, st);
+    case 2: return ws_launch_mt<T, 2, KS>(p, ngroup, st);
+    case 4: return ws_launch_mt<T, 4, KS>(p, ngroup, st);
+    case 5: return ws_launch_mt<T, 5, KS>(p, ngroup, st);
+    default: return ws_launch_mt<T, 8, KS>(p, ngroup, st);
+  }
+}
+
+// returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
+template <typename T>
+static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
+  int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 76 * 1024);
+  if (!nt) nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 156 * 1024);
+  if (!nt) return 0;
+  p.NTpack = conv_nt(p.Cout);
+  p.LSw = ws_ls(p.Kpad);
+  p.Ctot = 0; p.nsteps = 0;
+  for (int s2 = 0; s2 < p.nsrc; ++s2) { p.Ctot += p.srcC[s2]; p.nsteps += (p.srcC[s2] + 31) / 32; }
+  p.nsteps *= p.k * p.k;
+  if (p.nsrc == 1) { p.srcC[1] = p.srcC[0]; p.srcCs[1] = p.srcCs[0]; p.srcUp[1] = p.srcUp[0]; }
+  for (int s2 = 0; s2 < p.nsrc; ++s2) {
+    const int up = p.srcUp[s2];
+    const long npix = (long)p.B * (p.H >> up) * (p.W >> up);
+    const long bytes = ((npix - 1) * p.srcCs[s2] + p.srcC[s2] + (ngroup - 1) * p.srcG * 0) * (long)sizeof(T);
+    if (bytes >= (1L << 31) || p.srcG * (long)sizeof(T) * (ngroup - 1) >= (1L << 31)) return 0;  // beyond 32-bit buffer offsets: chunked kernel
+    p.srcBytes[s2] = (unsigned)bytes;
+  }
+  const bool ok = p.k == 1 ? ws_launch_nt<T, 1>(p, nt, ngroup, st) : ws_launch_nt<T, 3>(p, nt, ngroup, st);
+  if (!ok) return ey_set_error(EY_ELAUNCH, "conv: cannot reserve LDS for the weight tile");
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(ws): %s", hipGetErrorString(e_));
+  return 1;
 }
 
 template <typename T>
 static int dispatch_conv(const ConvP& p, int ngroup, hipStream_t st) {
+  bool ok;
   switch (conv_nt(p.Cout)) {
-    case 1: launch_conv<T, 1>(p, ngroup, st); break;
-    case 2: launch_conv<T, 2>(p, ngroup, st); break;
-    case 4: launch_conv<T, 4>(p, ngroup, st); break;
-    case 5: launch_conv<T, 5>(p, ngroup, st); break;
-    default: launch_conv<T, 8>(p, ngroup, st); break;
+    case 1: ok = launch_conv<T, 1>(p, ngroup, st); break;
+    case 2: ok = launch_conv<T, 2>(p, ngroup, st); break;
+    case 4: ok = launch_conv<T, 4>(p, ngroup, st); break;
+    case 5: ok = launch_conv<T, 5>(p, ngroup, st); break;
+    default: ok = launch_conv<T, 8>(p, ngroup, st); break;
   }
+  if (!ok) return ey_set_error(EY_ELAUNCH, "conv: cannot reserve LDS for the weight tile");
   EY_LAUNCH_CHECK("ey_conv2d");
   return EY_OK;
 }
@@ -296,9 +665,15 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   p.out_scale = d->out_scale; p.addz = d->addz; p.addzCs = d->addz_cstride; p.Hz = d->addz_H; p.Wz = d->addz_W;
   p.zsy = d->addz ? (float)d->addz_H / (float)d->Ho : 0.f; p.zsx = d->addz ? (float)d->addz_W / (float)d->Wo : 0.f; p.srcG = d->src_gstride; p.yG = d->y_gstride;
   p.Kpad = conv_kpad(Cin, d->k);
+  p.nchunks = 0;
+  for (int s2 = 0; s2 < d->nsrc; ++s2) p.nchunks += (d->src_C[s2] + CONV_CH - 1) / CONV_CH;
+  p.nchunks *= d->k * d->k;
   const int va = 4 * es;  // 4-element vector access alignment
   p.vec_store = d->Cout % 4 == 0 && (d->y_cstride * es) % va == 0 && ey_aligned(d->y, va) && (d->y_gstride * es) % va == 0 &&
-                (!d->res || ((d->res_cstride * es) % va == 0 && ey_aligned(d->res, va)));
+                (!d->res || ((d->res_cstride * es) % va == 0 && ey_aligned(d->res, va))) &&
+                (!d->addz || ((d->addz_cstride * es) % va == 0 && ey_aligned(d->addz, va))) && (!d->bias || ey_aligned(d->bias, 16));
   hipStream_t st = (hipStream_t)stream;
+  const int ws = d->dtype == EY_F16 ? dispatch_ws<f16>(p, ngroup, st) : dispatch_ws<float>(p, ngroup, st);
+  if (ws != 0) return ws < 0 ? ws : EY_OK;
   return d->dtype == EY_F16 ? dispatch_conv<f16>(p, ngroup, st) : dispatch_conv<float>(p, ngroup, st);
 }
