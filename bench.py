@@ -108,6 +108,7 @@ def main():
         return boxes, count
 
     runner = GraphRunner(device_step)
+    images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
     gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if world > 1 else None
 
     def step():

@@ -52,6 +52,7 @@ SIGNATURES = {
     "ey_conv2d_direct": (_i, [C.POINTER(ConvDirectDesc), _vp]),
     "ey_stem_conv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ey_dwconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "ey_dsconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dwt_haar": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ey_sppf_pool": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ey_copy_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
@@ -135,6 +136,8 @@ def is_nhwc_view(x):
 
 def as_nhwc(x):
     """Return an NHWC view of logical-NCHW x (no copy when it already is one)."""
+    if hasattr(x, "materialize"):  # nn._ops.VirtualCat reaching an operator that needs a real tensor
+        x = x.materialize()
     if x.dim() != 4:
         raise ValueError(f"expected a BCHW tensor, got shape {tuple(x.shape)}")
     if is_nhwc_view(x):

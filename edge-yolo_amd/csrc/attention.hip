@@ -5,7 +5,7 @@
 //   ctx[i][j] = sum_n ks[n][i] * v[n][j]     (d x d, fp32, lane j keeps column j in registers)
 //   qs[n][i] = softmax_n(q[:][i])            (over ALL pixels: two-pass column reduction, max/sum then normalise)
 //   y[n][j]  = sum_i qs[n][i] * ctx[i][j]
-// One workgroup (4 waves) per (image, head); N is streamed, so N=1600 (1280^2 input) needs no more LDS than N=400.
+// One workgroup (8 waves) per (image, head); N is streamed, so N=1600 (1280^2 input) needs no more LDS than N=400.
 #include "common.h"
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -19,10 +19,15 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// LA_WAVES waves per (image, head); a wave takes every LA_WAVES-th pixel.  Cross-lane traffic goes through per-wave LDS rows
+// (one broadcast ds_read_b128 feeds 4 FMAs) instead of 64 ds_bpermute per pixel.
+#define LA_WAVES 8
+#define LA_U 4
 template <typename T>
-__global__ __launch_bounds__(256) void linattn_kernel(int N, int C, int heads, int d, const T* __restrict__ qkv, int qCs, T* __restrict__ y, int yCs) {
-  __shared__ float ctx[64][65];
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * LA_WAVES) void linattn_kernel(int N, int C, int heads, int d, const T* __restrict__ qkv, int qCs, T* __restrict__ y, int yCs) {
+  __shared__ float ctx[64][64];
+  __shared__ float red[LA_WAVES][64];
+  __shared__ __attribute__((aligned(16))) float rowbuf[LA_WAVES][64];
   __shared__ float qmax[64], qsum[64];
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -32,54 +37,109 @@ __global__ __launch_bounds__(256) void linattn_kernel(int N, int C, int heads, i
   const T* kp = base + C;
   const T* vp = base + 2 * C;
 
-  // ---- q column statistics over N
+  // ---- q column statistics over N (max, then sum of exp)
+  // (pixel loops are unrolled by LA_U so that LA_U independent loads are in flight: each iteration is one dependent
+  //  round trip to L2/HBM otherwise)
   float m = -INFINITY;
-  for (int n = wave; n < N; n += 4) m = fmaxf(m, act ? to_f(qp[(long)n * qCs]) : -INFINITY);
+  for (int n0 = wave; n0 < N; n0 += LA_WAVES * LA_U) {
+    float t[LA_U];
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) { const int n = n0 + u * LA_WAVES; t[u] = (act && n < N) ? to_f(qp[(long)n * qCs]) : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) m = fmaxf(m, t[u]);
+  }
   red[wave][lane] = m;
+  for (int i = threadIdx.x; i < 64 * 64; i += 64 * LA_WAVES) ctx[i >> 6][i & 63] = 0.f;
   __syncthreads();
-  if (wave == 0) qmax[lane] = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+  if (wave == 0) {
+    float mm = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < LA_WAVES; ++w) mm = fmaxf(mm, red[w][lane]);
+    qmax[lane] = mm;
+  }
   __syncthreads();
   const float qm = qmax[lane];
   float s = 0.f;
-  for (int n = wave; n < N; n += 4) s += act ? __expf(to_f(qp[(long)n * qCs]) - qm) : 0.f;
-  __syncthreads();
+  for (int n0 = wave; n0 < N; n0 += LA_WAVES * LA_U) {
+    float t[LA_U];
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) { const int n = n0 + u * LA_WAVES; t[u] = (act && n < N) ? to_f(qp[(long)n * qCs]) : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) s += __expf(t[u] - qm);  // exp(-inf) = 0 for the masked ones
+  }
   red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0) qsum[lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0) {
+    float ss = 0.f;
+#pragma unroll
+    for (int w = 0; w < LA_WAVES; ++w) ss += red[w][lane];
+    qsum[lane] = ss;
+  }
 
-  // ---- ctx partial per wave: lane j accumulates column j
+  // ---- ctx partial per wave: lane j accumulates column j over this wave's pixels
   float col[64];
 #pragma unroll
   for (int i = 0; i < 64; ++i) col[i] = 0.f;
-  for (int n = wave; n < N; n += 4) {
-    const float kv = act ? to_f(kp[(long)n * qCs]) : -INFINITY;
-    const float vv = act ? to_f(vp[(long)n * qCs]) : 0.f;
-    const float km = wave_max(kv);
-    const float e = act ? __expf(kv - km) : 0.f;
-    const float ks = e / wave_sum(e);
+  float* rb = rowbuf[wave];
+  for (int n0 = wave; n0 < N; n0 += LA_WAVES * LA_U) {
+    float kk[LA_U], vu[LA_U];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) col[i] += __shfl(ks, i) * vv;
+    for (int u = 0; u < LA_U; ++u) {
+      const int n = n0 + u * LA_WAVES;
+      const bool ok = act && n < N;
+      kk[u] = ok ? to_f(kp[(long)n * qCs]) : -INFINITY;
+      vu[u] = ok ? to_f(vp[(long)n * qCs]) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) {
+      if (n0 + u * LA_WAVES >= N) break;  // wave-uniform
+      const float km = wave_max(kk[u]);
+      const float e = act ? __expf(kk[u] - km) : 0.f;
+      rb[lane] = e * __builtin_amdgcn_rcpf(wave_sum(e));
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i4 = 0; i4 < 16; ++i4) {
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(rb + 4 * i4);  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int j = 0; j < 4; ++j) col[4 * i4 + j] += k4[j] * vu[u];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  // reduce the 4 partial ctx through LDS
-  for (int w = 0; w < 4; ++w) {
+  // reduce the per-wave partial ctx in a FIXED wave order (deterministic sums; ctx was zeroed above)
+  for (int w = 0; w < LA_WAVES; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int i = 0; i < 64; ++i) ctx[i][lane] = (w == 0 ? 0.f : ctx[i][lane]) + col[i];
+      for (int i = 0; i < 64; ++i) ctx[i][lane] += col[i];
     }
     __syncthreads();
   }
 #pragma unroll
   for (int i = 0; i < 64; ++i) col[i] = ctx[i][lane];
-  const float qinv = 1.f / qsum[lane];
+  const float qinv = __builtin_amdgcn_rcpf(qsum[lane]);
 
   // ---- y = softmax_N(q) @ ctx
   T* yp = y + (long)b * N * yCs + h * d + lane;
-  for (int n = wave; n < N; n += 4) {
-    const float qs = act ? __expf(to_f(qp[(long)n * qCs]) - qm) * qinv : 0.f;
-    float o = 0.f;
+  for (int n0 = wave; n0 < N; n0 += LA_WAVES * LA_U) {
+    float qq[LA_U];
 #pragma unroll
-    for (int i = 0; i < 64; ++i) o += __shfl(qs, i) * col[i];
-    if (act) yp[(long)n * yCs] = from_f<T>(o);
+    for (int u = 0; u < LA_U; ++u) { const int n = n0 + u * LA_WAVES; qq[u] = (act && n < N) ? to_f(qp[(long)n * qCs]) : -INFINITY; }
+#pragma unroll
+    for (int u = 0; u < LA_U; ++u) {
+      const int n = n0 + u * LA_WAVES;
+      if (n >= N) break;  // wave-uniform
+      rb[lane] = __expf(qq[u] - qm) * qinv;
+      __builtin_amdgcn_wave_barrier();
+      float o = 0.f;
+#pragma unroll
+      for (int i4 = 0; i4 < 16; ++i4) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(rb + 4 * i4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o += q4[j] * col[4 * i4 + j];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act) yp[(long)n * yCs] = from_f<T>(o);
+    }
   }
 }
 
@@ -91,8 +151,8 @@ extern "C" int ey_linear_attention(int dtype, int B, int N, int C, int heads, co
   if (d > 64) return ey_set_error(EY_EUNSUPPORTED, "linear_attention: head_dim %d > 64", d);
   EY_CHECK(qkv_cstride >= 3 * C && y_cstride >= C, "linear_attention: cstride");
   dim3 grid(B * heads);
-  if (dtype == EY_F16) hipLaunchKernelGGL(linattn_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, N, C, heads, d, (const f16*)qkv, qkv_cstride, (f16*)y, y_cstride);
-  else hipLaunchKernelGGL(linattn_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, N, C, heads, d, (const float*)qkv, qkv_cstride, (float*)y, y_cstride);
+  if (dtype == EY_F16) hipLaunchKernelGGL(linattn_kernel<f16>, grid, dim3(64 * LA_WAVES), 0, (hipStream_t)stream, N, C, heads, d, (const f16*)qkv, qkv_cstride, (f16*)y, y_cstride);
+  else hipLaunchKernelGGL(linattn_kernel<float>, grid, dim3(64 * LA_WAVES), 0, (hipStream_t)stream, N, C, heads, d, (const float*)qkv, qkv_cstride, (float*)y, y_cstride);
   EY_LAUNCH_CHECK("ey_linear_attention");
   return EY_OK;
 }

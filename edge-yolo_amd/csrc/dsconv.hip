@@ -1,0 +1,266 @@
+// K2 — fused depthwise-separable convolution (DSConv.forward, reference nn/modules/conv.py:101-104):
+//     y = res + SiLU( BN( pw_1x1( dw_kxk(x) ) ) )        k in {3,5,7}, stride 1, pad k/2, BN folded into pw.
+// One persistent 256-thread workgroup walks 8x16-pixel output tiles:
+//   1. the (8+k-1) x (16+k-1) x Cin input halo tile is loaded ONCE into LDS (range-checked buffer loads give the
+//      zero padding for free);
+//   2. the depthwise stencil runs on the VALU out of LDS (fp32 accumulate, 2-pixel register strips so that every LDS
+//      vector feeds two outputs) and its result is written, rounded to the storage type exactly as the reference's
+//      intermediate tensor is, into an LDS pixel tile;
+//   3. the pointwise 1x1 is an MFMA GEMM over that tile against pw weights staged in LDS once per workgroup, with the
+//      same packed-weight layout and wide-store epilogue as the dense conv (bias, SiLU, residual).
+// The intermediate (B,C,H,W) tensor of the unfused form never touches HBM: x is read once, y written once.
+#include "common.h"
+
+struct DsP {
+  int B, H, W, Cin, Cout, act;
+  const void* x; int xCs; unsigned xBytes;
+  const void* wdw;   // [k][k][Cin] storage type
+  const void* wpw;   // packed by ey_conv_pack_weight(Cout, Cin, 1)
+  const float* bias; // [Cout] (folded BN) or null
+  void* y; int yCs;
+  const void* res; int resCs;
+  int Kpad, NTpack, tilesX, tilesY;
+  long ntile;
+  int vec_store;
+};
+
+__device__ __forceinline__ f32x4 ds_mma16(const Vec8<f16>& a, const Vec8<f16>& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ds_mma16(const Vec8<float>& a, const Vec8<float>& b, f32x4 c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+  return c;
+}
+
+#define DS_TH 8
+#define DS_TW 16
+
+template <typename T, int K, int NT>
+__global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HH = DS_TH + K - 1, HW = DS_TW + K - 1, BN = 16 * NT;
+  const int C = p.Cin, CV = C >> 3;
+  const int LSd = C + 8;       // dw-output tile row stride (elements)
+  const int LSw = p.Kpad + (((p.Kpad >> 3) & 1) ? 0 : 8);
+  float* s_in = reinterpret_cast<float*>(smem);  // [HH][HW][C]  fp32 (converted once on the way in)
+  float* s_wdw = s_in + HH * HW * C;             // [K*K][C]     fp32
+  T* s_dw = reinterpret_cast<T*>(s_wdw + K * K * C);  // [128][LSd]
+  T* s_wpw = s_dw + DS_TH * DS_TW * LSd;         // [BN][LSw]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * BN;
+
+  {  // weights: once per workgroup
+    const T* wg = (const T*)p.wpw + (long)n_base * p.Kpad;
+    const int kv = p.Kpad >> 3;
+    for (int v = tid; v < BN * kv; v += 256) {
+      const int row = v / kv, c8 = (v - row * kv) << 3;
+      Vec8<T> w;
+      w.load(wg + (long)row * p.Kpad + c8);
+      w.store(s_wpw + row * LSw + c8);
+    }
+    for (int v = tid; v < K * K * C; v += 256) s_wdw[v] = to_f(((const T*)p.wdw)[v]);
+  }
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(p.x, p.xBytes);
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  const int tiles_img = p.tilesX * p.tilesY;
+
+  for (long tile = blockIdx.x; tile < p.ntile; tile += gridDim.x) {
+    const int b = (int)(tile / tiles_img), trem = (int)(tile - (long)b * tiles_img);
+    const int ty0 = (trem / p.tilesX) * DS_TH, tx0 = (trem % p.tilesX) * DS_TW;
+    __syncthreads();  // previous tile's MFMA reads of s_dw / stencil reads of s_in are done (and weights are staged)
+    // ---- 1. halo tile -> LDS
+    for (int v = tid; v < HH * HW * CV; v += 256) {
+      const int cv = v % CV, px = v / CV, hx = px % HW, hy = px / HW;
+      const int iy = ty0 + hy - K / 2, ix = tx0 + hx - K / 2;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      Vec8<T> t;
+      BufLoad8<T>::load(t, rx, ok ? (unsigned)(((((long)b * p.H + iy) * p.W + ix) * p.xCs + cv * 8) * (long)sizeof(T)) : EY_OOB);
+      float* d = s_in + px * C + cv * 8;
+      const f32x4 lo = {t.get(0), t.get(1), t.get(2), t.get(3)}, hi = {t.get(4), t.get(5), t.get(6), t.get(7)};
+      *reinterpret_cast<f32x4*>(d) = lo;
+      *reinterpret_cast<f32x4*>(d + 4) = hi;
+    }
+    __syncthreads();
+    // ---- 2. depthwise stencil on fp32 LDS data: item = (row, 2-pixel strip, 4-channel group)
+    {
+      const int C4 = C >> 2;
+      for (int it = tid; it < DS_TH * (DS_TW / 2) * C4; it += 256) {
+        const int c4 = it % C4, sp = it / C4, xs = (sp % (DS_TW / 2)) * 2, y = sp / (DS_TW / 2);
+        f32x4 a0 = (f32x4)0.f, a1 = (f32x4)0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const float* row = s_in + ((y + ky) * HW + xs) * C + c4 * 4;
+          const float* wr = s_wdw + ky * K * C + c4 * 4;
+          f32x4 prev = *reinterpret_cast<const f32x4*>(row);
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const f32x4 nxt = *reinterpret_cast<const f32x4*>(row + (kx + 1) * C);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + kx * C);
+            a0 += prev * w;  // output pixel xs   reads column xs+kx
+            a1 += nxt * w;   // output pixel xs+1 reads column xs+kx+1
+            prev = nxt;
+          }
+        }
+        T* d0 = s_dw + (y * DS_TW + xs) * LSd + c4 * 4;
+        T* d1 = d0 + LSd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d0[i] = from_f<T>(a0[i]); d1[i] = from_f<T>(a1[i]); }
+      }
+    }
+    __syncthreads();
+    // ---- 3. pointwise GEMM: wave w owns tile rows 2w, 2w+1 (two 16-pixel m-blocks)
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+      const bool cok = (c0 + 8 * g) < C;
+      Vec8<T> bf[2], af[NT];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (cok) bf[mt].load(s_dw + ((2 * wave + mt) * DS_TW + r) * LSd + c0 + 8 * g);
+        else bf[mt].zero();
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) af[nt].load(s_wpw + (nt * 16 + r) * LSw + c0 + 8 * g);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = ds_mma16(af[nt], bf[mt], acc[mt][nt]);
+    }
+    // ---- epilogue: lane owns pixel (row 2w+mt, column r), channels ch0 .. ch0+4NT
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int oy = ty0 + 2 * wave + mt, ox = tx0 + r;
+      if (oy >= p.H || ox >= p.W) continue;
+      const long m = ((long)b * p.H + oy) * p.W + ox;
+      float v[4 * NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j];
+      const bool full = ch0 + 4 * NT <= p.Cout;
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i) {
+        const float bb = (p.bias && ch0 + i < p.Cout) ? p.bias[ch0 + i] : 0.f;
+        v[i] = ey_act(v[i] + bb, p.act);
+      }
+      T* yp = (T*)p.y + m * p.yCs + ch0;
+      const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
+      if (p.vec_store && full) {
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          float o[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+          if (rp) {
+            if constexpr (sizeof(T) == 2) {
+              const f16x4 rr = *reinterpret_cast<const f16x4*>(rp + 4 * q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] += (float)rr[j];
+            } else {
+              const f32x4 rr = *reinterpret_cast<const f32x4*>(rp + 4 * q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] += rr[j];
+            }
+          }
+          if constexpr (sizeof(T) == 2) {
+            const f16x4 ov = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+            *reinterpret_cast<f16x4*>(yp + 4 * q) = ov;
+          } else {
+            const f32x4 ov = {o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<f32x4*>(yp + 4 * q) = ov;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i)
+          if (ch0 + i < p.Cout) yp[i] = from_f<T>(v[i] + (rp ? to_f(rp[i]) : 0.f));
+      }
+    }
+  }
+}
+
+// mirrors conv_igemm.hip (same packing rule)
+static int ds_conv_nt(int Cout) {
+  if (Cout <= 16) return 1;
+  if (Cout <= 32) return 2;
+  if (Cout <= 64) return 4;
+  if (Cout <= 80) return 5;
+  if (Cout <= 128) return 8;
+  if (Cout % 128 == 0) return 8;
+  if (Cout % 80 == 0) return 5;
+  if (Cout % 64 == 0) return 4;
+  return 8;
+}
+
+template <typename T, int K, int NT>
+static int ds_launch(DsP p, hipStream_t st) {
+  const int C = p.Cin, HH = DS_TH + K - 1, HW = DS_TW + K - 1;
+  const int LSw = p.Kpad + (((p.Kpad >> 3) & 1) ? 0 : 8);
+  const size_t lds = ((size_t)HH * HW * C + (size_t)K * K * C) * 4 + ((size_t)DS_TH * DS_TW * (C + 8) + (size_t)16 * NT * LSw) * sizeof(T);
+  if (lds > 160 * 1024) return ey_set_error(EY_EUNSUPPORTED, "dsconv: Cin=%d k=%d needs %zu B of LDS", C, K, lds);
+  static size_t reserved = 0;
+  if (lds > 64 * 1024 && lds > reserved) {
+    if (hipFuncSetAttribute((const void*)dsconv_kernel<T, K, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "dsconv: cannot reserve %zu B of LDS", lds);
+    reserved = lds;
+  }
+  const int ntn = (p.Cout + 16 * NT - 1) / (16 * NT);
+  int per_cu = (int)((size_t)150 * 1024 / lds);  // resident workgroups per CU the LDS allows (the grid is persistent)
+  per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
+  long gx = (long)256 * per_cu / ntn;
+  if (gx < 1) gx = 1;
+  if (gx > p.ntile) gx = p.ntile;
+  hipLaunchKernelGGL((dsconv_kernel<T, K, NT>), dim3((unsigned)gx, ntn), dim3(256), lds, st, p);
+  EY_LAUNCH_CHECK("ey_dsconv");
+  return EY_OK;
+}
+
+template <typename T, int K>
+static int ds_launch_nt(const DsP& p, hipStream_t st) {
+  switch (p.NTpack) {
+    case 1: return ds_launch<T, K, 1>(p, st);
+    case 2: return ds_launch<T, K, 2>(p, st);
+    case 4: return ds_launch<T, K, 4>(p, st);
+    case 5: return ds_launch<T, K, 5>(p, st);
+    default: return ds_launch<T, K, 8>(p, st);
+  }
+}
+
+template <typename T>
+static int ds_launch_k(const DsP& p, int k, hipStream_t st) {
+  if (k == 3) return ds_launch_nt<T, 3>(p, st);
+  if (k == 5) return ds_launch_nt<T, 5>(p, st);
+  return ds_launch_nt<T, 7>(p, st);
+}
+
+extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,
+                         const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream) {
+  EY_CHECK(x && w_dw_kkc && w_pw_packed && y, "dsconv: null pointer");
+  EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "dsconv: bad dtype");
+  EY_CHECK(k == 3 || k == 5 || k == 7, "dsconv: k=%d (3,5,7)", k);
+  EY_CHECK(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "dsconv: bad extent");
+  EY_CHECK(Cin % 8 == 0 && Cin <= 256, "dsconv: Cin=%d must be a multiple of 8 and <= 256", Cin);
+  const int es = dtype == EY_F16 ? 2 : 4;
+  EY_CHECK(x_cstride >= Cin && (x_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(w_dw_kkc, 16) && ey_aligned(w_pw_packed, 16),
+           "dsconv: input view / weights must be 16-byte aligned");
+  EY_CHECK(y_cstride >= Cout && (!res || res_cstride >= Cout), "dsconv: cstride");
+  const long xbytes = (((long)B * H * W - 1) * x_cstride + Cin) * es;
+  if (xbytes >= (1L << 31)) return ey_set_error(EY_EUNSUPPORTED, "dsconv: input view larger than 2 GiB");
+  DsP p;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
+  p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)xbytes;
+  p.wdw = w_dw_kkc; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
+  p.Kpad = Cin + 32;
+  p.NTpack = ds_conv_nt(Cout);
+  p.tilesX = (W + DS_TW - 1) / DS_TW; p.tilesY = (H + DS_TH - 1) / DS_TH;
+  p.ntile = (long)B * p.tilesX * p.tilesY;
+  const int va = 4 * es;
+  p.vec_store = Cout % 4 == 0 && (y_cstride * es) % va == 0 && ey_aligned(y, va) && (!res || ((res_cstride * es) % va == 0 && ey_aligned(res, va)));
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == EY_F16 ? ds_launch_k<f16>(p, k, st) : ds_launch_k<float>(p, k, st);
+}

@@ -4,17 +4,48 @@
 // ============================================================================ head decode, one pyramid level
 // thread = one anchor.  64 box logits -> 4 x softmax(16) -> {DFL expectation, top-4 + mean -> FC(20->hid, ReLU)
 // -> FC(hid->1, sigmoid)} ; scores = sigmoid(cls) * clamp(q, 1e-6, 1-1e-6) ; boxes = xywh * stride.  All fp32.
+// 128 anchors per workgroup.  The anchors' logits are first staged into LDS with coalesced 16-byte loads (rows padded
+// to an odd number of 16-byte units, so the per-anchor row reads that follow are bank-conflict free); a thread then
+// decodes one anchor entirely from LDS and writes its 4+nc outputs, coalesced across threads, to pred (B,4+nc,A).
+#define HD_ANCH 128
 template <typename T>
-__global__ __launch_bounds__(256) void head_decode_kernel(int B, int H, int W, int nc, float stride, const T* __restrict__ box, int boxCs,
-                                                          const T* __restrict__ cls, int clsCs, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, int hid, float* __restrict__ pred, int A, int a_off) {
+__global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int W, int nc, float stride, const T* __restrict__ box, int boxCs,
+                                                              const T* __restrict__ cls, int clsCs, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ w2,
+                                                              const float* __restrict__ b2, int hid, float* __restrict__ pred, int A, int a_off,
+                                                              int boxLs, int clsLs, int vec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s_box = reinterpret_cast<T*>(smem);           // [HD_ANCH][boxLs]
+  T* s_cls = s_box + HD_ANCH * boxLs;              // [HD_ANCH][clsLs]
   const int HW = H * W;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)B * HW) return;
+  const long total = (long)B * HW;
+  const long idx0 = (long)blockIdx.x * HD_ANCH;
+  const int tid = threadIdx.x;
+  const int nrow = (int)min((long)HD_ANCH, total - idx0);
+  if (vec) {
+    for (int v = tid; v < nrow * 8; v += HD_ANCH) {  // 64 box logits = 8 vectors per anchor
+      const int row = v >> 3, c8 = (v & 7) << 3;
+      Vec8<T> t;
+      t.load(box + (idx0 + row) * boxCs + c8);
+      t.store(s_box + row * boxLs + c8);
+    }
+    const int cv = nc >> 3;
+    for (int v = tid; v < nrow * cv; v += HD_ANCH) {
+      const int row = v / cv, c8 = (v - row * cv) << 3;
+      Vec8<T> t;
+      t.load(cls + (idx0 + row) * clsCs + c8);
+      t.store(s_cls + row * clsLs + c8);
+    }
+  } else {
+    for (int v = tid; v < nrow * 64; v += HD_ANCH) { const int row = v >> 6, c = v & 63; s_box[row * boxLs + c] = box[(idx0 + row) * boxCs + c]; }
+    for (int v = tid; v < nrow * nc; v += HD_ANCH) { const int row = v / nc, c = v - row * nc; s_cls[row * clsLs + c] = cls[(idx0 + row) * clsCs + c]; }
+  }
+  __syncthreads();
+  if (tid >= nrow) return;
+  const long idx = idx0 + tid;
   const int b = (int)(idx / HW), a = (int)(idx - (long)b * HW);
   const int ay = a / W, ax = a - ay * W;
-  const T* bp = box + idx * boxCs;
+  const T* bp = s_box + tid * boxLs;
   float stat[20], dist[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -68,8 +99,23 @@ __global__ __launch_bounds__(256) void head_decode_kernel(int B, int H, int W, i
   pp[(long)A] = (y1 + y2) * 0.5f * stride;
   pp[2L * A] = (x2 - x1) * stride;
   pp[3L * A] = (y2 - y1) * stride;
-  const T* cp = cls + idx * clsCs;
-  for (int c = 0; c < nc; ++c) pp[(long)(4 + c) * A] = ey_sigmoid(to_f(cp[c])) * q;
+  const T* cp = s_cls + tid * clsLs;
+  if (vec) {
+    for (int c8 = 0; c8 < nc; c8 += 8) {
+      Vec8<T> t;
+      t.load(cp + c8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pp[(long)(4 + c8 + i) * A] = ey_sigmoid(t.get(i)) * q;
+    }
+  } else {
+    for (int c = 0; c < nc; ++c) pp[(long)(4 + c) * A] = ey_sigmoid(to_f(cp[c])) * q;
+  }
+}
+
+static int hd_pad(int elems, int es) {  // row stride (elements): 16-byte aligned, odd number of 16-byte units
+  int units = (elems * es + 15) / 16;
+  if (!(units & 1)) ++units;
+  return units * 16 / es;
 }
 
 extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const void* box, int box_cstride, const void* cls,
@@ -79,17 +125,27 @@ extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stri
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "head_decode: bad dtype");
   EY_CHECK(B > 0 && H > 0 && W > 0 && nc > 0, "head_decode: bad extent");
   EY_CHECK(box_cstride >= 64 && cls_cstride >= nc, "head_decode: cstride");
-  EY_CHECK((box_cstride * (dtype == EY_F16 ? 2 : 4)) % 16 == 0 && ey_aligned(box, 16), "head_decode: box view must be 16-byte aligned");
   EY_CHECK(a_off >= 0 && a_off + H * W <= A_total, "head_decode: level [%d,%d) outside A=%d", a_off, a_off + H * W, A_total);
   EY_CHECK(!q_w1 || (q_b1 && q_w2 && q_b2 && q_hidden > 0), "head_decode: incomplete quality head");
+  const int es = dtype == EY_F16 ? 2 : 4;
+  const int vec = nc % 8 == 0 && (box_cstride * es) % 16 == 0 && (cls_cstride * es) % 16 == 0 && ey_aligned(box, 16) && ey_aligned(cls, 16);
+  const int boxLs = hd_pad(64, es), clsLs = hd_pad(nc, es);
+  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es;
+  EY_CHECK(lds <= 160 * 1024, "head_decode: nc=%d needs %zu B of LDS", nc, lds);
   const long total = (long)B * H * W;
-  dim3 grid((unsigned)((total + 255) / 256));
-  if (dtype == EY_F16)
-    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, nc, stride, (const f16*)box, box_cstride, (const f16*)cls,
-                       cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off);
-  else
-    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, B, H, W, nc, stride, (const float*)box, box_cstride,
-                       (const float*)cls, cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off);
+  dim3 grid((unsigned)((total + HD_ANCH - 1) / HD_ANCH));
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EY_F16) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(HD_ANCH), lds, st, B, H, W, nc, stride, (const f16*)box, box_cstride, (const f16*)cls,
+                       cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, boxLs, clsLs, vec);
+  } else {
+    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(HD_ANCH), lds, st, B, H, W, nc, stride, (const float*)box, box_cstride,
+                       (const float*)cls, cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, boxLs, clsLs, vec);
+  }
   EY_LAUNCH_CHECK("ey_head_decode");
   return EY_OK;
 }

@@ -60,9 +60,15 @@ class GraphRunner:
                 out = self.fn(static_in)
             g = self.graphs[key] = (graph, static_in, out)
         graph, static_in, out = g
-        static_in.copy_(x, non_blocking=True)
+        if x.data_ptr() != static_in.data_ptr():  # callers that fill static_input() in place skip the copy
+            static_in.copy_(x, non_blocking=True)
         graph.replay()
         return out
+
+    def static_input(self, like):
+        """The captured graph's input buffer for tensors shaped like `like` (captures on first use)."""
+        self(like)
+        return self.graphs[(tuple(like.shape), like.dtype, like.device)][1]
 
 
 class DetectionPredictor:

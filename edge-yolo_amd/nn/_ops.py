@@ -33,6 +33,35 @@ def _dev_key(x, tag=""):
     return (tag, x.dtype, x.device)
 
 
+class VirtualCat:
+    """Channel concat of NHWC tensors that is never written: `parts` = [(tensor, up)], `up`=1 meaning "read through a
+    nearest x2 upsample".  Produced by Upsample / Concat when the graph knows the consumer is a 1x1 conv (layers
+    11-12, 14-15, 18, 21 of the YAMLs); the conv kernel walks the sources directly (K7 folded into K1)."""
+
+    def __init__(self, parts):
+        self.parts = parts
+        t, u = parts[0]
+        self.shape = (t.shape[0], sum(p.shape[1] for p, _ in parts), t.shape[2] << u, t.shape[3] << u)
+        self.dtype, self.device = t.dtype, t.device
+        self.is_cuda = t.is_cuda
+
+    def dim(self):
+        return 4
+
+    def materialize(self):
+        B, c, H, W = self.shape
+        out = L.empty_nhwc(B, c, H, W, self.dtype, self.device)
+        c0 = 0
+        for t, u in self.parts:
+            copy_slice(L.as_nhwc(t), out[:, c0:c0 + t.shape[1]], up=u)
+            c0 += t.shape[1]
+        return out
+
+
+def as_tensor(x):
+    return x.materialize() if isinstance(x, VirtualCat) else x
+
+
 def pack_conv_weight(w_oihw, dtype, device):
     """fp32 OIHW -> packed MFMA layout (host side, ey_conv_pack_weight) -> device."""
     w = w_oihw.detach().float().cpu().contiguous()
@@ -59,6 +88,12 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
     """y = res + out_scale*act(conv(cat(srcs)) + bias + up2x(addz)).  srcs: list of 1-2 logical-NCHW tensors
     (source i is read through a nearest x2 upsample when up[i]).  With ngroup>1 `srcs[0]`/`out` are the group-0
     slices and *_gstride the element offsets between groups (channel count per group = group_C)."""
+    if len(srcs) == 1 and isinstance(srcs[0], VirtualCat):
+        vc = srcs[0]
+        if k == 1 and len(vc.parts) <= 2 and up is None:
+            srcs, up = [t for t, _ in vc.parts], [u for _, u in vc.parts]
+        else:
+            srcs = [vc.materialize()]
     x0 = srcs[0]
     L.require_device(x0, "conv2d")
     srcs = [L.as_nhwc(t) for t in srcs]
@@ -196,6 +231,41 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     return out
 
 
+def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None):
+    """Fused DSConv: y = res + act(pw1x1(dw_kxk(x)) + bias).  Returns None when the shape is outside the fused kernel
+    (caller then runs the two-kernel form)."""
+    L.require_device(x, "dsconv")
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    es = x.element_size()
+    if c % 8 or c > 256 or (L.cstride(x) * es) % 16 or x.data_ptr() % 16:
+        return None
+
+    def build():
+        wd, bd = dw_fn()
+        if bd is not None:
+            return None
+        wp, bp = pw_fn()
+        wk = wd.view(c, k, k).permute(1, 2, 0).contiguous().to(device=x.device, dtype=x.dtype)
+        return wk, pack_conv_weight(wp, x.dtype, x.device), (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0]
+
+    pk = mod._packed(_dev_key(x, "dsfused"), build)
+    if pk is None:
+        return None
+    wk, wp, bias, cout = pk
+    if out is None:
+        out = L.empty_nhwc(B, cout, H, W, x.dtype, x.device)
+    elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, H, W):
+        raise ValueError("dsconv: out= must be an NHWC view of the output shape")
+    if res is not None:
+        res = L.as_nhwc(res)
+    with _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}"):
+        L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), wp.data_ptr(),
+                                  bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out),
+                                  res.data_ptr() if res is not None else None, L.cstride(res) if res is not None else 0, L.stream()), "ey_dsconv")
+    return out
+
+
 def dwt_haar(x, out=None):
     """(B,C,H,W) -> (B,4C,H/2,W/2) with channel blocks LL|LH|HL|HH."""
     L.require_device(x, "dwt_haar")
@@ -229,7 +299,7 @@ def copy_slice(src, dst, up=0):
 
 
 def concat(xs):
-    xs = [L.as_nhwc(t) for t in xs]
+    xs = [L.as_nhwc(as_tensor(t)) for t in xs]
     L.require_device(xs[0], "concat")
     B, _, H, W = xs[0].shape
     out = L.empty_nhwc(B, sum(t.shape[1] for t in xs), H, W, xs[0].dtype, xs[0].device)
@@ -243,7 +313,7 @@ def concat(xs):
 
 
 def upsample2x(x):
-    x = L.as_nhwc(x)
+    x = L.as_nhwc(as_tensor(x))
     L.require_device(x, "upsample2x")
     B, c, H, W = x.shape
     return copy_slice(x, L.empty_nhwc(B, c, 2 * H, 2 * W, x.dtype, x.device), up=1)

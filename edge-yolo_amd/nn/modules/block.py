@@ -57,8 +57,7 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
     def forward(self, x, out=None):
-        x = L.as_nhwc(x)
-        B, _, H, W = x.shape
+        B, _, H, W = x.shape  # x may be a VirtualCat (upsample+concat folded into cv1)
         c, n = self.c, len(self.m)
         buf = L.empty_nhwc(B, (2 + n) * c, H, W, x.dtype, x.device)
         self.cv1(x, out=buf[:, :2 * c])
@@ -366,8 +365,7 @@ class DSC3K2_Wavelet(nn.Module):
         self.wave = _WaveletEnhancer(self.c, use_ds=use_ds, wave=wave, mode=mode)
 
     def forward(self, x, out=None):
-        x = L.as_nhwc(x)
-        B, _, H, W = x.shape
+        B, _, H, W = x.shape  # x may be a VirtualCat (upsample+concat folded into cv1)
         c, n = self.c, len(self.m)
         t = self.cv1(x)  # [a | b]
         buf = L.empty_nhwc(B, (1 + n) * c, H, W, x.dtype, x.device)  # [wave(b) | m_0 | ...]

@@ -102,7 +102,7 @@ class Conv(_Packed):
             raise NotImplementedError("non-square kernels / dilation are outside the EdgeLine-YOLO detection path")
         act = _act_code(self.act)
         if (g == 1 and k == 3 and s == 2 and p == 1 and c.in_channels <= 4 and c.out_channels % 16 == 0 and res is None
-                and x.dim() == 4 and x.is_contiguous() and not L.is_nhwc_view(x)):
+                and torch.is_tensor(x) and x.dim() == 4 and x.is_contiguous() and not L.is_nhwc_view(x)):
             # network stem: read the planar NCHW image directly, write NHWC
             return ops.stem_conv(self, x, self.folded, act, x.dtype, out=out)
         if g == 1:
@@ -144,12 +144,19 @@ class DSConv(_Packed):
         k, s, d = self.dw.kernel_size[0], self.dw.stride[0], self.dw.dilation[0]
         if s != 1 or d != 1 or self.dw.padding[0] != k // 2:
             raise NotImplementedError("DSConv with stride/dilation != 1 is outside the EdgeLine-YOLO detection path")
+        y = ops.dsconv(self, x, self._dw_folded, self._pw_folded, k, L.ACT_SILU, out=out, res=res)  # one fused kernel
+        if y is not None:
+            return y
         t = ops.dwconv(self, x, self._dw_folded, k, L.ACT_NONE, tag="dw")
         return ops.conv2d(self, [t], self._pw_folded, 1, 1, 0, L.ACT_SILU, out=out, res=res, tag="pw")
 
 
 class Concat(nn.Module):
-    """Channel concat (reference conv.py:345-355).  Module-level form: slice copies on the device."""
+    """Channel concat (reference conv.py:345-355).  Stand-alone it copies slices on the device and returns a tensor;
+    inside a DetectionModel whose consumer starts with a 1x1 conv (`lazy=True`, set by the graph builder) it returns a
+    VirtualCat that the conv reads in place."""
+
+    lazy = False
 
     def __init__(self, dimension=1):
         super().__init__()
@@ -158,6 +165,12 @@ class Concat(nn.Module):
     def forward(self, x):
         if self.d != 1:
             raise NotImplementedError("Concat along dim != 1")
+        if self.lazy:
+            parts = []
+            for t in x:
+                parts += t.parts if isinstance(t, ops.VirtualCat) else [(t, 0)]
+            if len(parts) <= 2:
+                return ops.VirtualCat(parts)
         return ops.concat(x)
 
 
@@ -170,5 +183,9 @@ class Upsample(nn.Module):
             raise NotImplementedError("only nearest x2 upsampling is on the detection path")
         self.scale_factor, self.mode = scale_factor, mode
 
+    lazy = False
+
     def forward(self, x):
+        if self.lazy and torch.is_tensor(x):
+            return ops.VirtualCat([(x, 1)])
         return ops.upsample2x(x)

@@ -198,11 +198,34 @@ class DetectionModel(BaseModel):
             # needing a device at construction time.
             m.stride = torch.tensor(self._graph_strides(ch))
             self.stride = m.stride
+        self._fold_upsample_concat()
         for mod in self.modules():  # initialize_weights (utils/torch_utils.py:410-420)
             if isinstance(mod, nn.BatchNorm2d):
                 mod.eps = 1e-3
                 mod.momentum = 0.03
         self.eval()
+
+    def _fold_upsample_concat(self):
+        """K7: mark Upsample/Concat layers whose every consumer starts with a 1x1 conv as lazy: they then hand a
+        VirtualCat to that conv instead of writing the upsampled / concatenated tensor (never changes results)."""
+        from .modules import C2PSA, C2PSA_LinearAttention
+        consumers = {}
+        for m in self.model:
+            for j in ([m.f] if isinstance(m.f, int) else m.f):
+                consumers.setdefault((m.i + j) if j < 0 else j, []).append(m)
+
+        def takes_virtual(m):
+            if isinstance(m, (C2f, DSC3K2_Wavelet, C2PSA, C2PSA_LinearAttention)):
+                return True
+            return isinstance(m, Conv) and m.conv.kernel_size == (1, 1) and m.conv.groups == 1
+
+        for m in self.model:
+            if isinstance(m, Concat) and m.i not in self.save:
+                m.lazy = all(takes_virtual(c) for c in consumers.get(m.i, [])) and bool(consumers.get(m.i))
+        for m in self.model:
+            if isinstance(m, Upsample) and m.i not in self.save:
+                cs = consumers.get(m.i, [])
+                m.lazy = bool(cs) and all(isinstance(c, Concat) and c.lazy for c in cs)
 
     def _graph_strides(self, ch):
         down = []
