@@ -52,7 +52,7 @@ SIGNATURES = {
     "ey_conv2d_direct": (_i, [C.POINTER(ConvDirectDesc), _vp]),
     "ey_stem_conv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ey_dwconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
-    "ey_dsconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ey_dsconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dwt_haar": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ey_sppf_pool": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ey_copy_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -275,14 +275,21 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
   const int r = lane & 15, g = lane >> 4;
   const int n_base = blockIdx.y * BN;
   const int grp = blockIdx.z;
-  {
+  {  // 8 independent 16-byte loads in flight per thread, then the LDS stores
     const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
-    const int kv = p.Kpad >> 3;
-    for (int v = threadIdx.x; v < BN * kv; v += 512) {
-      const int row = v / kv, c8 = (v - row * kv) << 3;
-      Vec8<T> w;
-      w.load(wg + (long)row * p.Kpad + c8);
-      w.store(wl + row * p.LSw + c8);
+    const int kv = p.Kpad >> 3, nvec = BN * kv;
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
+      Vec8<T> w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * 512;
+        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].load(wg + (long)row * p.Kpad + c8); }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * 512;
+        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].store(wl + row * p.LSw + c8); }
+      }
     }
   }
   __syncthreads();
@@ -499,7 +506,7 @@ extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const fl
 // which instantiation ey_conv2d picks: returns NT*16 + MT (profiling / documentation only)
 extern "C" int ey_conv_tile(int Cout, long M, int ngroup) {
   (void)ngroup;
-  return conv_nt(Cout) * 16 + (M >= 65536 ? 2 : 1);  // packing NT; the kernel may use a divisor of it when LDS is short
+  return conv_nt(Cout) * 16 + (M >= 300000 ? 2 : 1);  // packing NT; the kernel may use a divisor of it when LDS is short
 }
 
 template <typename T, int NT, int MT>
@@ -570,7 +577,7 @@ template <typename T, int NT, int KS>
 static bool ws_launch_mt(const ConvP& p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   // enough wave tiles to give every SIMD work: 2 pixel blocks per wave when M is large, else 1
-  if (M >= 65536) return ws_launch<T, NT, 2, KS>(p, ngroup, st);
+  if (M >= 300000) return ws_launch<T, NT, 2, KS>(p, ngroup, st);  // measured: below this, more (smaller) wave tiles hide latency better
   return ws_launch<T, NT, 1, KS>(p, ngroup, st);
 }
 

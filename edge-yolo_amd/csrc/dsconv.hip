@@ -15,6 +15,7 @@ struct DsP {
   int B, H, W, Cin, Cout, act;
   const void* x; int xCs; unsigned xBytes;
   const void* wdw;   // [k][k][Cin] storage type
+  const float* dwbias; int dwact;  // optional bias + activation between the depthwise and the pointwise conv (DWConv -> Conv towers)
   const void* wpw;   // packed by ey_conv_pack_weight(Cout, Cin, 1)
   const float* bias; // [Cout] (folded BN) or null
   void* y; int yCs;
@@ -107,8 +108,13 @@ __global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
         }
         T* d0 = s_dw + (y * DS_TW + xs) * LSd + c4 * 4;
         T* d1 = d0 + LSd;
+        if (p.dwbias) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(p.dwbias + c4 * 4);
+          a0 += bb;
+          a1 += bb;
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { d0[i] = from_f<T>(a0[i]); d1[i] = from_f<T>(a1[i]); }
+        for (int i = 0; i < 4; ++i) { d0[i] = from_f<T>(ey_act(a0[i], p.dwact)); d1[i] = from_f<T>(ey_act(a1[i], p.dwact)); }
       }
     }
     __syncthreads();
@@ -239,7 +245,7 @@ static int ds_launch_k(const DsP& p, int k, hipStream_t st) {
 }
 
 extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,
-                         const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream) {
+                         const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream) {
   EY_CHECK(x && w_dw_kkc && w_pw_packed && y, "dsconv: null pointer");
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "dsconv: bad dtype");
   EY_CHECK(k == 3 || k == 5 || k == 7, "dsconv: k=%d (3,5,7)", k);
@@ -249,12 +255,13 @@ extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int 
   EY_CHECK(x_cstride >= Cin && (x_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(w_dw_kkc, 16) && ey_aligned(w_pw_packed, 16),
            "dsconv: input view / weights must be 16-byte aligned");
   EY_CHECK(y_cstride >= Cout && (!res || res_cstride >= Cout), "dsconv: cstride");
+  EY_CHECK(!dw_bias || ey_aligned(dw_bias, 16), "dsconv: dw_bias must be 16-byte aligned");
   const long xbytes = (((long)B * H * W - 1) * x_cstride + Cin) * es;
   if (xbytes >= (1L << 31)) return ey_set_error(EY_EUNSUPPORTED, "dsconv: input view larger than 2 GiB");
   DsP p;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
   p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)xbytes;
-  p.wdw = w_dw_kkc; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
+  p.wdw = w_dw_kkc; p.dwbias = dw_bias; p.dwact = dw_act; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
   p.Kpad = Cin + 32;
   p.NTpack = ds_conv_nt(Cout);
   p.tilesX = (W + DS_TW - 1) / DS_TW; p.tilesY = (H + DS_TH - 1) / DS_TH;

@@ -231,9 +231,9 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     return out
 
 
-def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None):
-    """Fused DSConv: y = res + act(pw1x1(dw_kxk(x)) + bias).  Returns None when the shape is outside the fused kernel
-    (caller then runs the two-kernel form)."""
+def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
+    """Fused depthwise->pointwise: y = res + act(pw1x1(dw_act(dw_kxk(x) + dw_bias)) + bias).  Returns None when the shape is
+    outside the fused kernel (caller then runs the two-kernel form)."""
     L.require_device(x, "dsconv")
     x = L.as_nhwc(x)
     B, c, H, W = x.shape
@@ -243,26 +243,26 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None):
 
     def build():
         wd, bd = dw_fn()
-        if bd is not None:
-            return None
         wp, bp = pw_fn()
         wk = wd.view(c, k, k).permute(1, 2, 0).contiguous().to(device=x.device, dtype=x.dtype)
-        return wk, pack_conv_weight(wp, x.dtype, x.device), (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0]
+        return (wk, (bd.to(x.device).float().contiguous() if bd is not None else None), pack_conv_weight(wp, x.dtype, x.device),
+                (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0])
 
-    pk = mod._packed(_dev_key(x, "dsfused"), build)
-    if pk is None:
-        return None
-    wk, wp, bias, cout = pk
+    wk, dwb, wp, bias, cout = mod._packed(_dev_key(x, "dsfused"), build)
     if out is None:
         out = L.empty_nhwc(B, cout, H, W, x.dtype, x.device)
     elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, H, W):
         raise ValueError("dsconv: out= must be an NHWC view of the output shape")
     if res is not None:
         res = L.as_nhwc(res)
-    with _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}"):
-        L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), wp.data_ptr(),
+    try:
+      with _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}"):
+        L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
+                                  dwb.data_ptr() if dwb is not None else None, dw_act, wp.data_ptr(),
                                   bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out),
                                   res.data_ptr() if res is not None else None, L.cstride(res) if res is not None else 0, L.stream()), "ey_dsconv")
+    except NotImplementedError:  # EY_EUNSUPPORTED is returned before anything is launched (tile does not fit LDS): two-kernel form
+        return None
     return out
 
 

@@ -81,8 +81,22 @@ class Detect(nn.Module):
         c = self.cv3[i]
         t = x
         for j in range(len(c) - 1):
-            t = c[j](t)
+            t = c[j](t)  # (self._dw_pw fuses DWConv+Conv into one kernel; measured slower than the two kernels at these widths)
         self._tail(c[-1]).run(t, raw[:, 4 * self.reg_max:])
+
+    @staticmethod
+    def _dw_pw(blk, t):
+        """Sequential(DWConv 3x3 (+BN+SiLU), Conv 1x1 (+BN+SiLU)) of the non-legacy cls tower (reference head.py:68-69) as
+        ONE fused depthwise->pointwise kernel; anything else runs module by module."""
+        if isinstance(blk, nn.Sequential) and len(blk) == 2 and isinstance(blk[0], DWConv) and isinstance(blk[1], Conv):
+            dw, pw = blk[0].conv, blk[1].conv
+            k = dw.kernel_size[0]
+            if (dw.groups == dw.in_channels == dw.out_channels and dw.stride == (1, 1) and k in (3, 5, 7) and dw.padding == (k // 2, k // 2)
+                    and pw.kernel_size == (1, 1) and pw.groups == 1 and isinstance(blk[0].act, nn.SiLU) and isinstance(blk[1].act, nn.SiLU)):
+                y = ops.dsconv(blk[1], t, blk[0].folded, blk[1].folded, k, L.ACT_SILU, dw_act=L.ACT_SILU)
+                if y is not None:
+                    return y
+        return blk(t)
 
     def _quality_params(self, i, device):
         return None

@@ -106,11 +106,14 @@ int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cou
 int ey_dwconv(int dtype, int B, int H, int W, int C, int k, int act, const void* x, int x_cstride, const void* w_kkc,
               const float* bias, void* y, int y_cstride, ey_stream_t stream);
 
-/* ---- K2 fused: DSConv.forward (conv.py:101-104) in one kernel: y = res + act(pw1x1(dw_kxk(x)) + bias), BN folded into
- * the pointwise weights/bias.  The depthwise result stays in LDS (rounded to `dtype` like the reference's intermediate).
- * w_dw: [k][k][Cin] in `dtype`; w_pw: ey_conv_pack_weight(dtype, Cout, Cin, 1, ...); k in {3,5,7}; Cin%8==0, Cin<=256. */
+/* ---- K2/K3 fused: depthwise kxk -> pointwise 1x1 in one kernel:
+ *   y = res + act( pw1x1( dw_act( dw_kxk(x) + dw_bias ) ) + bias )
+ * = DSConv.forward (conv.py:101-104; dw_bias NULL, dw_act NONE, BN folded into pw) and the Detect.cv3 pairs
+ * DWConv(BN+SiLU) -> Conv 1x1 (head.py:68-69).  The depthwise result stays in LDS (rounded to `dtype` like the
+ * reference's intermediate tensor).  w_dw: [k][k][Cin] in `dtype`; dw_bias fp32 [Cin] or NULL;
+ * w_pw: ey_conv_pack_weight(dtype, Cout, Cin, 1, ...); k in {3,5,7}; Cin%8==0, Cin<=256. */
 int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride,
-              const void* w_dw_kkc, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res,
+              const void* w_dw_kkc, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res,
               int res_cstride, ey_stream_t stream);
 
 /* ---- K4: single-level 2-D Haar analysis (_PywtDWT2D.forward, block.py:3619-3642).
