@@ -503,12 +503,6 @@ extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const fl
   return EY_OK;
 }
 
-// which instantiation ey_conv2d picks: returns NT*16 + MT (profiling / documentation only)
-extern "C" int ey_conv_tile(int Cout, long M, int ngroup) {
-  (void)ngroup;
-  return conv_nt(Cout) * 16 + (M >= 300000 ? 2 : 1);  // packing NT; the kernel may use a divisor of it when LDS is short
-}
-
 template <typename T, int NT, int MT>
 static bool conv_lds_ok() {  // one-time opt-in to > 64 KiB of dynamic LDS for the big-tile / f32 variants
   static const bool ok = [] {
@@ -684,3 +678,16 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   if (ws != 0) return ws < 0 ? ws : EY_OK;
   return d->dtype == EY_F16 ? dispatch_conv<f16>(p, ngroup, st) : dispatch_conv<float>(p, ngroup, st);
 }
+
+// Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only):
+// returns kind*1000 + NT*10 + MT with kind 1 = conv_ws_kernel<T,NT,MT,k> (weight-stationary), 0 = conv_igemm_kernel<T,NT,MT>.
+extern "C" int ey_conv_variant(int dtype, int Cout, int Cin, int k, long M, int ngroup) {
+  const int es = dtype == EY_F16 ? 2 : 4, Kpad = conv_kpad(Cin, k);
+  int nt = ws_pick_nt(Cout, Kpad, es, 76 * 1024);
+  if (!nt) nt = ws_pick_nt(Cout, Kpad, es, 156 * 1024);
+  if (nt) return 1000 + nt * 10 + (M >= 300000 ? 2 : 1);
+  nt = conv_nt(Cout);
+  const int ntiles = (Cout + 16 * nt - 1) / (16 * nt);
+  return nt * 10 + ((M + 127) / 128 * ntiles * (ngroup > 0 ? ngroup : 1) >= 512 ? 2 : 1);
+}
+extern "C" int ey_conv_pack_nt(int Cout) { return conv_nt(Cout); }

@@ -150,9 +150,11 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
     if TRACE is not None:
         M = B * Ho * Wo
         es = x0.element_size()
-        tile = L.lib().ey_conv_tile(cout, M, ngroup)
+        var = L.lib().ey_conv_variant(d.dtype, cout, cin, k, M, ngroup)
+        tn = "f16" if es == 2 else "f32"
+        name = (f"conv_ws_kernel<{tn},{var % 1000 // 10},{var % 10},{k}>" if var >= 1000 else f"conv_igemm_kernel<{tn},{var // 10},{var % 10}>")
         nbytes = ngroup * (_nb(*srcs) + M * cout * es * (2 if res is not None else 1) + _nb(addz)) + cout * cin * k * k * es
-        with _tr(f"conv_igemm_kernel<{'f16' if es == 2 else 'f32'},{tile >> 4},{tile & 15}>", nbytes, 2.0 * ngroup * M * cout * cin * k * k,
+        with _tr(name, nbytes, 2.0 * ngroup * M * cout * cin * k * k,
                  note=f"{cin}->{cout} k{k}s{s} {H}x{W} g{ngroup}{' +res' if res is not None else ''}{' +addz' if addz is not None else ''}{' 2src' if len(srcs) > 1 else ''}"):
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
         return out

@@ -95,7 +95,7 @@ def test_weight_packing_layout(cout, cin, k):
     assert L.lib().ey_conv_pack_weight(L.F32, cout, cin, k, w.data_ptr(), buf.data_ptr(), nbytes) == 0
     kp = k * k * cin + 32
     p = buf.view(torch.float32).view(-1, kp)
-    nt = (L.lib().ey_conv_tile(cout, 1 << 20, 1)) >> 4
+    nt = L.lib().ey_conv_pack_nt(cout)
     bn = 16 * nt
     seen = set()
     for row in range(p.shape[0]):
