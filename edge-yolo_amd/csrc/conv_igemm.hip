@@ -36,6 +36,7 @@ struct ConvP {
   int NTpack;    // NT the weights were packed with (row permutation), see ey_conv_pack_weight
   int LSw;       // LDS row stride (elements) of the weight-stationary kernel
   long ntile;    // number of wave tiles (16*MT pixels each)
+  int ntn;       // number of channel tiles (small-M kernel)
   int vec_store; // 1: y/res/addz views are aligned for 4-element vector access
 };
 
@@ -260,6 +261,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 }
 
+// Shared epilogue: lane owns pixel m = (b, oy, ox) and output channels ch0 .. ch0+4NT of it.
+template <typename T, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4 (&acc)[NT], long m, int b, int oy, int ox, int ch0, int grp) {
+  float v[4 * NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[nt][j];
+  const bool full = ch0 + 4 * NT <= p.Cout;
+  if (p.bias) {
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] += bv[j];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout) v[i] += p.bias[ch0 + i];
+    }
+  }
+  if (p.addz) {
+    // F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen area_pixel_compute_source_index, scale = in/out
+    const int Hz = p.Hz, Wz = p.Wz;
+    const float sy = fmaxf(p.zsy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(p.zsx * (ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
+    const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const T* z = (const T*)p.addz + (long)grp * p.yG;
+    const T* z00 = z + (((long)b * Hz + y0) * Wz + x0) * p.addzCs + ch0;
+    const T* z01 = z + (((long)b * Hz + y0) * Wz + x1) * p.addzCs + ch0;
+    const T* z10 = z + (((long)b * Hz + y1) * Wz + x0) * p.addzCs + ch0;
+    const T* z11 = z + (((long)b * Hz + y1) * Wz + x1) * p.addzCs + ch0;
+    if (p.vec_store && full) {
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        float a00[4], a01[4], a10[4], a11[4];
+        load4(z00 + 4 * q, a00); load4(z01 + 4 * q, a01); load4(z10 + 4 * q, a10); load4(z11 + 4 * q, a11);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i)
+        if (ch0 + i < p.Cout)
+          v[i] += ly0 * (lx0 * to_f(z00[i]) + lx1 * to_f(z01[i])) + ly1 * (lx0 * to_f(z10[i]) + lx1 * to_f(z11[i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+  T* yp = (T*)p.y + (long)grp * p.yG + m * p.yCs + ch0;
+  const T* rp = p.res ? (const T*)p.res + (long)grp * p.yG + m * p.resCs + ch0 : nullptr;
+  if (p.vec_store && full) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      if (rp) {
+        float rr[4];
+        load4(rp + 4 * q, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * q + j] += rr[j];
+      }
+      store4(yp + 4 * q, v + 4 * q);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i)
+      if (ch0 + i < p.Cout) yp[i] = from_f<T>(v[i] + (rp ? to_f(rp[i]) : 0.f));
+  }
+}
+
 // ================================================================================================================
 // Weight-stationary persistent variant (the default): each 512-thread workgroup stages its whole weight tile
 // [16*NT rows][K] into LDS ONCE (zero-padded rows, odd 16-byte stride -> conflict-free ds_read_b128) and then its 8
@@ -386,79 +459,211 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
       }
     }
 
-    // ---- epilogue (same math as conv_igemm_kernel's)
+    // ---- epilogue
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       if (!pv[mt]) continue;
-      const long m = m0 + mt * 16 + r;
-      float v[4 * NT];
+      conv_epilogue<T, NT>(p, acc[mt], m0 + mt * 16 + r, pb[mt], poy[mt], pox[mt], ch0, grp);
+    }
+  }
+}
+
+// ================================================================================================================
+// 3x3 halo-tile variant (single source, Cin <= 64): the 9 taps of a 3x3 window re-read every input pixel up to nine
+// times; from global memory that is 9x the L2->L1 traffic of the layer.  Here a 512-thread workgroup owns a tile of
+// 8 output rows x 16*MT columns (wave w = row w): the (7S+3) x ((16MT-1)S+3) x Cin input halo goes to LDS once per
+// tile (range-checked buffer loads: zero padding for free; the NEXT tile's halo is already in flight in registers
+// while this one is multiplied), weights are LDS-resident for the whole kernel, and both MFMA operands are
+// ds_read_b128.  Pixel rows are padded to an odd number of 16-byte units -> conflict-free fragment reads at stride 1.
+template <typename T, int NT, int S>
+__global__ __launch_bounds__(512) void conv3_halo_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BN = 16 * NT, MT = (S == 1) ? 2 : 1, TR = 8, TC = 16 * MT;
+  constexpr int HR = (TR - 1) * S + 3, HC = (TC - 1) * S + 3;
+  const int C = p.srcC[0], CV = C >> 3, CP = C + 8;
+  constexpr int HV = 10;  // halo vectors per thread held in registers (>= HR*HC*CV/512 for Cin <= 64)
+  T* wl = reinterpret_cast<T*>(smem);
+  T* hl = wl + BN * p.LSw;  // [HR*HC][CP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * BN, grp = blockIdx.z;
+  {
+    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    const int kv = p.Kpad >> 3, nvec = BN * kv;
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
+      Vec8<T> w[8];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j];
-      const bool full = ch0 + 4 * NT <= p.Cout;
-      if (p.bias) {
-        if (full) {
-#pragma unroll
-          for (int q = 0; q < NT; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * q + j] += bv[j];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4 * NT; ++i)
-            if (ch0 + i < p.Cout) v[i] += p.bias[ch0 + i];
-        }
-      }
-      if (p.addz) {
-        const int Hz = p.Hz, Wz = p.Wz;
-        const float sy = fmaxf(p.zsy * (poy[mt] + 0.5f) - 0.5f, 0.f), sx = fmaxf(p.zsx * (pox[mt] + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
-        const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const T* z = (const T*)p.addz + (long)grp * p.yG;
-        const T* z00 = z + (((long)pb[mt] * Hz + y0) * Wz + x0) * p.addzCs + ch0;
-        const T* z01 = z + (((long)pb[mt] * Hz + y0) * Wz + x1) * p.addzCs + ch0;
-        const T* z10 = z + (((long)pb[mt] * Hz + y1) * Wz + x0) * p.addzCs + ch0;
-        const T* z11 = z + (((long)pb[mt] * Hz + y1) * Wz + x1) * p.addzCs + ch0;
-        if (p.vec_store && full) {
-#pragma unroll
-          for (int q = 0; q < NT; ++q) {
-            float a00[4], a01[4], a10[4], a11[4];
-            load4(z00 + 4 * q, a00); load4(z01 + 4 * q, a01); load4(z10 + 4 * q, a10); load4(z11 + 4 * q, a11);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * q + j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4 * NT; ++i)
-            if (ch0 + i < p.Cout)
-              v[i] += ly0 * (lx0 * to_f(z00[i]) + lx1 * to_f(z01[i])) + ly1 * (lx0 * to_f(z10[i]) + lx1 * to_f(z11[i]));
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * 512;
+        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].load(wg + (long)row * p.Kpad + c8); }
       }
 #pragma unroll
-      for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
-      T* yp = (T*)p.y + (long)grp * p.yG + m * p.yCs + ch0;
-      const T* rp = p.res ? (const T*)p.res + (long)grp * p.yG + m * p.resCs + ch0 : nullptr;
-      if (p.vec_store && full) {
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-          if (rp) {
-            float rr[4];
-            load4(rp + 4 * q, rr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[4 * q + j] += rr[j];
-          }
-          store4(yp + 4 * q, v + 4 * q);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4 * NT; ++i)
-          if (ch0 + i < p.Cout) yp[i] = from_f<T>(v[i] + (rp ? to_f(rp[i]) : 0.f));
+      for (int u = 0; u < 8; ++u) {
+        const int v = v0 + u * 512;
+        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].store(wl + row * p.LSw + c8); }
       }
     }
   }
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  const int tilesX = (p.Wo + TC - 1) / TC, tilesY = (p.Ho + TR - 1) / TR, tiles_img = tilesX * tilesY;
+  const long ntile = (long)p.B * tiles_img;
+  const int nhv = HR * HC * CV;  // halo vectors per tile
+
+  // this thread's halo vectors: LDS offset and (hy,hx,c8) are tile independent
+  int hoff[HV], hyx[HV];
+#pragma unroll
+  for (int u = 0; u < HV; ++u) {
+    const int v = threadIdx.x + u * 512;
+    const int px = v / CV, cv = v - px * CV;
+    hoff[u] = v < nhv ? px * CP + cv * 8 : -1;
+    hyx[u] = ((px / HC) << 16) | ((px % HC) << 4) | 0;
+    hyx[u] = (hyx[u] & ~0xF) | 0;  // (c8 recomputed from hoff)
+  }
+  auto issue_halo = [&](long tile, Vec8<T> (&hv)[HV]) {
+    const int b = (int)(tile / tiles_img), tr = (int)(tile - (long)b * tiles_img);
+    const int iy0 = (tr / tilesX) * TR * S - 1, ix0 = (tr % tilesX) * TC * S - 1;
+#pragma unroll
+    for (int u = 0; u < HV; ++u) {
+      if (hoff[u] >= 0) {
+        const int hy = hyx[u] >> 16, hx = (hyx[u] >> 4) & 0xFFF;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int c8 = hoff[u] - (hy * HC + hx) * CP;
+        BufLoad8<T>::load(hv[u], rs, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.srcCs[0] + c8) * (int)sizeof(T)) : EY_OOB);
+      }
+    }
+  };
+
+  Vec8<T> hv[HV];
+  long tile = blockIdx.x;
+  if (tile < ntile) issue_halo(tile, hv);
+  const T* wlane = wl + r * p.LSw + 8 * g;
+  for (; tile < ntile; tile += gridDim.x) {
+    __syncthreads();  // weights staged (first pass) / every wave finished reading the previous halo
+#pragma unroll
+    for (int u = 0; u < HV; ++u)
+      if (hoff[u] >= 0) hv[u].store(hl + hoff[u]);
+    __syncthreads();
+    const long nxt = tile + gridDim.x;
+    if (nxt < ntile) issue_halo(nxt, hv);  // in flight during the MFMAs below
+
+    const int b = (int)(tile / tiles_img), tr = (int)(tile - (long)b * tiles_img);
+    const int oy = (tr / tilesX) * TR + wave, ox0 = (tr % tilesX) * TC;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
+    const T* hlane = hl + ((wave * S) * HC + r * S) * CP + 8 * g;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        for (int c0 = 0; c0 < C; c0 += 32) {
+          const bool cok = (c0 + 8 * g) < C;
+          Vec8<T> bf[MT], af[NT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            if (cok) bf[mt].load(hlane + (ky * HC + mt * 16 * S + kx) * CP + c0);
+            else bf[mt].zero();
+          }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) af[nt].load(wlane + nt * 16 * p.LSw + (ky * 3 + kx) * C + c0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt], acc[mt][nt]);
+        }
+      }
+    }
+    if (oy < p.Ho) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int ox = ox0 + mt * 16 + r;
+        if (ox < p.Wo) conv_epilogue<T, NT>(p, acc[mt], ((long)b * p.Ho + oy) * p.Wo + ox, b, oy, ox, ch0, grp);
+      }
+    }
+  }
+}
+
+// ================================================================================================================
+// Small-M variant (feature maps of 40x40 and below: M = B*Ho*Wo is a few 10^4 pixels).  Such layers are pure latency:
+// a kernel that first stages weights into LDS, synchronises, then loads pixels pays 4-5 dependent memory round trips
+// for a few microseconds of work.  Here a wave owns one 16-pixel block x 16*NT channels, there is no LDS and no
+// barrier, and the fragment loads of up to BATCH k-steps (pixels by range-checked buffer loads, weights straight
+// from the L2-resident packed array) are all in flight before the first MFMA: one round trip per BATCH*32 channels.
+template <typename T, int NT, int BATCH>
+__global__ __launch_bounds__(256) void conv_small_kernel(ConvP p) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int ntn = p.ntn;
+  const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n_tile = (int)(wid % ntn);
+  const long m_tile = wid / ntn;
+  if (m_tile >= p.ntile) return;  // whole wave
+  const int grp = blockIdx.z;
+  const int n_base = n_tile * 16 * NT;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const long m = m_tile * 16 + r;
+  const bool pv = m < M;
+  const int hw = p.Ho * p.Wo;
+  const long mm = pv ? m : 0;
+  const int b = (int)(mm / hw), rem = (int)(mm - (long)b * hw), oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+
+  const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
+  const __amdgpu_buffer_rsrc_t rs1 = p.nsrc > 1 ? ey_rsrc(p.src[1], p.srcBytes[1]) : rs0;
+  int base[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int up = p.srcUp[s], Hs = p.H >> up, Ws = p.W >> up;  // up==1 only with k==1
+    base[s] = (((b * Hs + (iy0 >> up)) * Ws + (ix0 >> up)) * p.srcCs[s] + 8 * g) * (int)sizeof(T);
+  }
+  unsigned tapmask = 0;
+  for (int t = 0; t < p.k * p.k; ++t) {
+    const int iy = iy0 + t / p.k, ix = ix0 + t % p.k;
+    tapmask |= (unsigned)(pv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) << t;
+  }
+  const T* wl = (const T*)p.w + (long)(n_base + r) * p.Kpad + 8 * g;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+
+  int s_ = 0, tap = 0, c = 0;  // wave-uniform K cursor: (tap, source, channel)
+  for (int step0 = 0; step0 < p.nsteps; step0 += BATCH) {
+    Vec8<T> bf[BATCH], af[BATCH][NT];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      if (step0 + u < p.nsteps) {
+        const int ky = tap / p.k, kx = tap - ky * p.k;
+        const int Cs = p.srcC[s_];
+        const bool ok = ((tapmask >> tap) & 1u) && (c + 8 * g) < Cs;
+        const unsigned off = ok ? (unsigned)(base[s_] + ((ky * p.W + kx) * p.srcCs[s_] + c) * (int)sizeof(T)) : EY_OOB;
+        if (s_) BufLoad8<T>::load(bf[u], rs1, off);
+        else BufLoad8<T>::load(bf[u], rs0, off);
+        const int kofs = tap * p.Ctot + (s_ ? p.srcC[0] : 0) + c;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) af[u][nt].load(wl + (long)nt * 16 * p.Kpad + kofs);
+        c += 32;
+        if (c >= Cs) {
+          c = 0;
+          if (++s_ >= p.nsrc) { s_ = 0; ++tap; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      if (step0 + u < p.nsteps) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mma16(af[u][nt], bf[u], acc[nt]);
+      }
+    }
+  }
+  if (!pv) return;
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, grp);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -586,6 +791,125 @@ static bool ws_launch_nt(const ConvP& p, int nt, int ngroup, hipStream_t st) {
   }
 }
 
+// ---- 3x3 halo-tile dispatch
+template <typename T, int NT, int S>
+static int halo_launch(ConvP p, int ngroup, hipStream_t st) {
+  constexpr int MT = (S == 1) ? 2 : 1, TR = 8, TC = 16 * MT, HR = (TR - 1) * S + 3, HC = (TC - 1) * S + 3;
+  const int C = p.srcC[0];
+  const size_t lds = ((size_t)16 * NT * p.LSw + (size_t)HR * HC * (C + 8)) * sizeof(T);
+  static size_t reserved = 0;
+  if (lds > 64 * 1024 && lds > reserved) {
+    if (hipFuncSetAttribute((const void*)conv3_halo_kernel<T, NT, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "conv: cannot reserve %zu B of LDS for the halo tile", lds);
+    reserved = lds;
+  }
+  const long ntile = (long)p.B * ((p.Wo + TC - 1) / TC) * ((p.Ho + TR - 1) / TR);
+  const int ntn = conv_cout_pad(p.Cout) / (16 * NT);
+  const int per_cu = lds > 78 * 1024 ? 1 : 2;
+  long gx = (long)256 * per_cu / ((long)ntn * ngroup);
+  if (gx < 1) gx = 1;
+  if (gx > ntile) gx = ntile;
+  hipLaunchKernelGGL((conv3_halo_kernel<T, NT, S>), dim3((unsigned)gx, ntn, ngroup), dim3(512), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(halo): %s", hipGetErrorString(e_));
+  return 1;
+}
+
+// largest NT dividing the packing NT such that weights + halo fit LDS; 0 = does not fit
+template <typename T>
+static int halo_pick_nt(const ConvP& p, int S) {
+  const int MT = (S == 1) ? 2 : 1, TC = 16 * MT, HR = 7 * S + 3, HC = (TC - 1) * S + 3, C = p.srcC[0];
+  const size_t halo = (size_t)HR * HC * (C + 8) * sizeof(T);
+  const int ntp = conv_nt(p.Cout);
+  for (int i = 0; i < 5; ++i) {
+    const int nt = WS_NT[i];
+    if (nt > ntp || ntp % nt) continue;
+    if (halo + (size_t)16 * nt * ws_ls(p.Kpad) * sizeof(T) <= 158 * 1024) return nt;
+  }
+  return 0;
+}
+
+template <typename T>
+static int dispatch_halo(ConvP p, int ngroup, hipStream_t st) {
+  if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || p.srcC[0] > 64 || p.srcC[0] < 48) return 0;  // measured: wins for Cin=64 on large maps
+  const int S = p.stride;
+  {  // the per-thread register halo holds HV=10 vectors
+    const int MT = (S == 1) ? 2 : 1, HR = 7 * S + 3, HC = (16 * MT - 1) * S + 3;
+    if ((long)HR * HC * (p.srcC[0] >> 3) > 512L * 10) return 0;
+  }
+  const long npix = (long)p.B * p.H * p.W;
+  const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * (long)sizeof(T);
+  if (bytes >= (1L << 31) || p.srcG * (long)sizeof(T) * (ngroup - 1) >= (1L << 31)) return 0;
+  p.srcBytes[0] = (unsigned)bytes;
+  p.NTpack = conv_nt(p.Cout);
+  p.LSw = ws_ls(p.Kpad);
+  const int nt = halo_pick_nt<T>(p, S);
+  if (!nt) return 0;
+#define HALO(NTV)                                                     \
+  case NTV: return S == 1 ? halo_launch<T, NTV, 1>(p, ngroup, st) : halo_launch<T, NTV, 2>(p, ngroup, st);
+  switch (nt) {
+    HALO(1) HALO(2) HALO(4) HALO(5) HALO(8)
+  }
+#undef HALO
+  return 0;
+}
+
+// ---- small-M dispatch
+template <typename T, int NT>
+static int small_launch(ConvP p, int ngroup, hipStream_t st) {
+  constexpr int BATCH = sizeof(T) == 2 ? 8 : 4;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  p.ntile = (M + 15) / 16;
+  p.ntn = conv_cout_pad(p.Cout) / (16 * NT);
+  const long waves = p.ntile * p.ntn;
+  hipLaunchKernelGGL((conv_small_kernel<T, NT, BATCH>), dim3((unsigned)((waves + 3) / 4), 1, ngroup), dim3(256), 0, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(small): %s", hipGetErrorString(e_));
+  return 1;
+}
+
+static int small_pick_nt(int Cout, int es) {
+  const int ntp = conv_nt(Cout);
+  const int cap = es == 2 ? 5 : 2;
+  const int opts[4] = {5, 4, 2, 1};
+  for (int i = 0; i < 4; ++i)
+    if (opts[i] <= cap && opts[i] <= ntp && ntp % opts[i] == 0) return opts[i];
+  return 1;
+}
+
+// The latency-oriented kernel wins (measured) for 1x1 convs on small maps as long as the weights every wave re-reads
+// from L2 stay a small total: (#16-pixel tiles) x (weight bytes) <= 48 MB.  Larger weights: weight-stationary kernel.
+#define EY_SMALL_M 100000
+static bool small_ok(int Cout, int Kpad, int k, long M, int es) {
+  if (k != 1 || M >= EY_SMALL_M) return false;
+  return ((M + 15) / 16) * (long)conv_cout_pad(Cout) * Kpad * es <= 48L * 1024 * 1024;
+}
+
+template <typename T>
+static int dispatch_small(ConvP p, int ngroup, hipStream_t st) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  if (!small_ok(p.Cout, p.Kpad, p.k, M, sizeof(T))) return 0;
+  p.Ctot = 0; p.nsteps = 0;
+  for (int s2 = 0; s2 < p.nsrc; ++s2) {
+    p.Ctot += p.srcC[s2];
+    p.nsteps += (p.srcC[s2] + 31) / 32;
+    const int up = p.srcUp[s2];
+    const long npix = (long)p.B * (p.H >> up) * (p.W >> up);
+    const long bytes = ((npix - 1) * p.srcCs[s2] + p.srcC[s2]) * (long)sizeof(T);
+    if (bytes >= (1L << 31) || p.srcG * (long)sizeof(T) * (ngroup - 1) >= (1L << 31)) return 0;
+    p.srcBytes[s2] = (unsigned)bytes;
+  }
+  p.nsteps *= p.k * p.k;
+  if (p.nsrc == 1) { p.srcC[1] = p.srcC[0]; p.srcCs[1] = p.srcCs[0]; p.srcUp[1] = p.srcUp[0]; p.src[1] = p.src[0]; }
+  p.NTpack = conv_nt(p.Cout);
+  switch (small_pick_nt(p.Cout, sizeof(T))) {
+    case 5: if constexpr (sizeof(T) == 2) return small_launch<T, 5>(p, ngroup, st); else return small_launch<T, 1>(p, ngroup, st);
+    case 4: if constexpr (sizeof(T) == 2) return small_launch<T, 4>(p, ngroup, st); else return small_launch<T, 2>(p, ngroup, st);
+    case 2: return small_launch<T, 2>(p, ngroup, st);
+    default: return small_launch<T, 1>(p, ngroup, st);
+  }
+}
+
 // returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
 template <typename T>
 static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
@@ -674,15 +998,30 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
                 (!d->res || ((d->res_cstride * es) % va == 0 && ey_aligned(d->res, va))) &&
                 (!d->addz || ((d->addz_cstride * es) % va == 0 && ey_aligned(d->addz, va))) && (!d->bias || ey_aligned(d->bias, 16));
   hipStream_t st = (hipStream_t)stream;
+  const int sm = d->dtype == EY_F16 ? dispatch_small<f16>(p, ngroup, st) : dispatch_small<float>(p, ngroup, st);
+  if (sm != 0) return sm < 0 ? sm : EY_OK;
+  const int halo = d->dtype == EY_F16 ? dispatch_halo<f16>(p, ngroup, st) : dispatch_halo<float>(p, ngroup, st);
+  if (halo != 0) return halo < 0 ? halo : EY_OK;
   const int ws = d->dtype == EY_F16 ? dispatch_ws<f16>(p, ngroup, st) : dispatch_ws<float>(p, ngroup, st);
   if (ws != 0) return ws < 0 ? ws : EY_OK;
   return d->dtype == EY_F16 ? dispatch_conv<f16>(p, ngroup, st) : dispatch_conv<float>(p, ngroup, st);
 }
 
-// Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only):
-// returns kind*1000 + NT*10 + MT with kind 1 = conv_ws_kernel<T,NT,MT,k> (weight-stationary), 0 = conv_igemm_kernel<T,NT,MT>.
-extern "C" int ey_conv_variant(int dtype, int Cout, int Cin, int k, long M, int ngroup) {
+// Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only): kind*1000 + NT*10 + MT,
+// kind 3 = conv_small_kernel<T,NT,BATCH> (last digit = BATCH), 2 = conv3_halo_kernel<T,NT,stride>,
+// 1 = conv_ws_kernel<T,NT,MT,k>, 0 = conv_igemm_kernel<T,NT,MT>.
+extern "C" int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_single_source, long M, int ngroup) {
   const int es = dtype == EY_F16 ? 2 : 4, Kpad = conv_kpad(Cin, k);
+  if (small_ok(Cout, Kpad, k, M, es)) return 3000 + small_pick_nt(Cout, es) * 10 + (es == 2 ? 8 : 4);
+  if (k == 3 && plain_single_source && Cin <= 64 && Cin >= 48) {
+    ConvP p;
+    p.Cout = Cout; p.srcC[0] = Cin; p.Kpad = Kpad;
+    const int MT = stride == 1 ? 2 : 1, HR = 7 * stride + 3, HC = (16 * MT - 1) * stride + 3;
+    if ((long)HR * HC * (Cin >> 3) <= 512L * 10) {
+      const int nt = es == 2 ? halo_pick_nt<f16>(p, stride) : halo_pick_nt<float>(p, stride);
+      if (nt) return 2000 + nt * 10 + MT;
+    }
+  }
   int nt = ws_pick_nt(Cout, Kpad, es, 76 * 1024);
   if (!nt) nt = ws_pick_nt(Cout, Kpad, es, 156 * 1024);
   if (nt) return 1000 + nt * 10 + (M >= 300000 ? 2 : 1);

@@ -211,11 +211,13 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 //  Stops at max_det kept, max_nms candidates, or when the keys are exhausted.  Cost follows the number of
 //  candidates actually needed, not A: no full sort.
 #define NMS_CAP 4096
-#define NMS_TARGET 1024
+#define NMS_TARGET 2048
 
 struct NmsShared {
   unsigned hist[4096];
   unsigned long long chunk[NMS_CAP];
+  KeptBox wbox[16][64];            // per wave: its 64 candidates' boxes (broadcast reads in the pairwise pass)
+  unsigned long long wsup[16][64];  // per wave: bit i of wsup[j] = candidate i (earlier, alive) suppresses candidate j
   int sel_lo, cnt, nkept, processed;
 };
 
@@ -359,39 +361,63 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
         x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
         area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
       }
+      // pairwise pass, all 16 waves at once: bit i of mysup = "earlier candidate i of my wave overlaps me beyond the
+      // threshold" (independent of who survives; survival is applied in the scan below)
+      S.wbox[wave][lane] = KeptBox{x1, y1, x2, y2, area};
+      __builtin_amdgcn_wave_barrier();
+      unsigned long long mysup = 0ull;
+      if (alive) {
+#pragma unroll 4
+        for (int i = 0; i < 63; ++i) {
+          const KeptBox bi = S.wbox[wave][i];
+          if (i < lane && iou_gt(bi.x1, bi.y1, bi.x2, bi.y2, bi.area, x1, y1, x2, y2, area, iou_thres)) mysup |= 1ull << i;
+        }
+      }
+      const unsigned sup_lo = (unsigned)mysup, sup_hi = (unsigned)(mysup >> 32);
       int checked = 0;
       const int nwaves = min(16, (n - sb + 63) >> 6);
       for (int w = 0; w < nwaves; ++w) {
         __syncthreads();
         const int nk = S.nkept;
         if (nk >= max_det) break;
-        if (wave >= w) {  // catch up with boxes kept since this candidate was last tested
-          for (int k = checked; k < nk && alive; ++k) {
-            const KeptBox kb = kept[k];
-            if (iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, x1, y1, x2, y2, area, iou_thres)) alive = false;
+        if (wave >= w) {  // catch up with boxes kept since this candidate was last tested (4 at a time: no serial LDS chain)
+          bool sup = false;
+          int k = checked;
+          for (; k + 4 <= nk; k += 4) {
+            const KeptBox k0 = kept[k], k1 = kept[k + 1], k2 = kept[k + 2], k3 = kept[k + 3];
+            sup |= iou_gt(k0.x1, k0.y1, k0.x2, k0.y2, k0.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k1.x1, k1.y1, k1.x2, k1.y2, k1.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k2.x1, k2.y1, k2.x2, k2.y2, k2.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k3.x1, k3.y1, k3.x2, k3.y2, k3.area, x1, y1, x2, y2, area, iou_thres);
           }
+          for (; k < nk; ++k) {
+            const KeptBox kb = kept[k];
+            sup |= iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, x1, y1, x2, y2, area, iou_thres);
+          }
+          alive = alive && !sup;
           checked = nk;
         }
-        if (wave == w) {  // resolve this wave's 64 candidates in score order
-          int nkk = nk;
-          bool pending = alive;
-          while (nkk < max_det) {
-            const unsigned long long am = __ballot(pending);
-            if (am == 0ull) break;
-            const int s = __ffsll((unsigned long long)am) - 1;
-            const float sx1 = __shfl(x1, s), sy1 = __shfl(y1, s), sx2 = __shfl(x2, s), sy2 = __shfl(y2, s), sarea = __shfl(area, s);
-            if (lane == s) {
-              kept[nkk] = KeptBox{x1, y1, x2, y2, area};
-              float* ob = out_boxes + ((long)b * max_det + nkk) * 6;
-              ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
-              if (out_index) out_index[(long)b * max_det + nkk] = a;
-              pending = false;
-            } else if (pending && lane > s) {
-              if (iou_gt(sx1, sy1, sx2, sy2, sarea, x1, y1, x2, y2, area, iou_thres)) { pending = false; alive = false; }
-            }
-            ++nkk;
+        if (wave == w) {
+          // Resolve this wave's 64 candidates: "keep j iff no KEPT earlier candidate suppresses it" is a scan over the
+          // pairwise bit masks; the masks are pulled lane by lane with v_readlane (wave-uniform index), so the whole
+          // dependent chain runs on the scalar unit.
+          const unsigned long long am = __ballot(alive);
+          unsigned long long keptm = 0ull;
+          for (unsigned long long mbits = am; mbits; mbits &= mbits - 1) {
+            const int j = __ffsll((unsigned long long)mbits) - 1;
+            const unsigned long long sj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)sup_hi, j) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)sup_lo, j);
+            if ((sj & keptm) == 0ull) keptm |= 1ull << j;
           }
-          if (lane == 0) S.nkept = nkk;
+          const int rank = nk + __popcll(keptm & ((1ull << lane) - 1ull));
+          const bool keep = ((keptm >> lane) & 1ull) && rank < max_det;
+          if (keep) {
+            kept[rank] = KeptBox{x1, y1, x2, y2, area};
+            float* ob = out_boxes + ((long)b * max_det + rank) * 6;
+            ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
+            if (out_index) out_index[(long)b * max_det + rank] = a;
+          }
+          if (lane == 0) S.nkept = min(max_det, nk + __popcll(keptm));
         }
       }
     }

@@ -150,9 +150,11 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
     if TRACE is not None:
         M = B * Ho * Wo
         es = x0.element_size()
-        var = L.lib().ey_conv_variant(d.dtype, cout, cin, k, M, ngroup)
+        var = L.lib().ey_conv_variant(d.dtype, cout, cin, k, s, int(len(srcs) == 1 and not up[0]), M, ngroup)
         tn = "f16" if es == 2 else "f32"
-        name = (f"conv_ws_kernel<{tn},{var % 1000 // 10},{var % 10},{k}>" if var >= 1000 else f"conv_igemm_kernel<{tn},{var // 10},{var % 10}>")
+        name = (f"conv_small_kernel<{tn},{var % 1000 // 10},{var % 10}>" if var >= 3000 else
+                f"conv3_halo_kernel<{tn},{var % 1000 // 10},{s}>" if var >= 2000 else
+                f"conv_ws_kernel<{tn},{var % 1000 // 10},{var % 10},{k}>" if var >= 1000 else f"conv_igemm_kernel<{tn},{var // 10},{var % 10}>")
         nbytes = ngroup * (_nb(*srcs) + M * cout * es * (2 if res is not None else 1) + _nb(addz)) + cout * cin * k * k * es
         with _tr(name, nbytes, 2.0 * ngroup * M * cout * cin * k * k,
                  note=f"{cin}->{cout} k{k}s{s} {H}x{W} g{ngroup}{' +res' if res is not None else ''}{' +addz' if addz is not None else ''}{' 2src' if len(srcs) > 1 else ''}"):

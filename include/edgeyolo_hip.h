@@ -81,9 +81,10 @@ size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k);
  * MFMA epilogue, + zero slack).  Upload `out` to the device afterwards. */
 int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const float* w_oihw_host, void* out_host, size_t out_bytes);
 int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream);
-/* Kernel instantiation ey_conv2d launches for a shape (profiling only): kind*1000 + NT*10 + MT, kind 1 =
- * conv_ws_kernel<T,NT,MT,k> (weight-stationary persistent), kind 0 = conv_igemm_kernel<T,NT,MT> (K-chunked fallback). */
-int ey_conv_variant(int dtype, int Cout, int Cin, int k, long M, int ngroup);
+/* Kernel instantiation ey_conv2d launches for a shape (profiling only): kind*1000 + NT*10 + MT, kind 2 =
+ * conv3_halo_kernel<T,NT,stride> (3x3, LDS halo tile), 1 = conv_ws_kernel<T,NT,MT,k> (weight-stationary persistent),
+ * 0 = conv_igemm_kernel<T,NT,MT> (K-chunked fallback).  plain_single_source = one source, no upsample. */
+int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_single_source, long M, int ngroup);
 /* NT the weights of a Cout-channel conv are packed with (row permutation of ey_conv_pack_weight). */
 int ey_conv_pack_nt(int Cout);
 
