@@ -15,20 +15,18 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int 
                                                               const float* __restrict__ b2, int hid, float* __restrict__ pred, int A, int a_off,
                                                               int boxLs, int clsLs, int vec) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  T* s_box = reinterpret_cast<T*>(smem);           // [HD_ANCH][boxLs]
+  T* s_box = reinterpret_cast<T*>(smem);           // [HD_ANCH][boxLs]  (scalar path only: boxLs == 0 on the vector path)
   T* s_cls = s_box + HD_ANCH * boxLs;              // [HD_ANCH][clsLs]
+  float* s_w1 = reinterpret_cast<float*>(s_cls + HD_ANCH * clsLs);  // [hid][20] quality FC1 (+ b1[hid], w2[hid] behind it)
+  float* s_b1 = s_w1 + hid * 20;
+  float* s_w2 = s_b1 + hid;
   const int HW = H * W;
   const long total = (long)B * HW;
   const long idx0 = (long)blockIdx.x * HD_ANCH;
   const int tid = threadIdx.x;
   const int nrow = (int)min((long)HD_ANCH, total - idx0);
   if (vec) {
-    for (int v = tid; v < nrow * 8; v += HD_ANCH) {  // 64 box logits = 8 vectors per anchor
-      const int row = v >> 3, c8 = (v & 7) << 3;
-      Vec8<T> t;
-      t.load(box + (idx0 + row) * boxCs + c8);
-      t.store(s_box + row * boxLs + c8);
-    }
+    // (box logits: each thread reads its own anchor's 64 contiguous values straight from global, 8 x 16 B in flight)
     const int cv = nc >> 3;
     for (int v = tid; v < nrow * cv; v += HD_ANCH) {
       const int row = v / cv, c8 = (v - row * cv) << 3;
@@ -40,12 +38,16 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int 
     for (int v = tid; v < nrow * 64; v += HD_ANCH) { const int row = v >> 6, c = v & 63; s_box[row * boxLs + c] = box[(idx0 + row) * boxCs + c]; }
     for (int v = tid; v < nrow * nc; v += HD_ANCH) { const int row = v / nc, c = v - row * nc; s_cls[row * clsLs + c] = cls[(idx0 + row) * clsCs + c]; }
   }
+  if (w1) {  // the quality-head weights are read by every thread: LDS broadcast instead of dependent scalar loads
+    for (int v = tid; v < hid * 20; v += HD_ANCH) s_w1[v] = w1[v];
+    for (int v = tid; v < hid; v += HD_ANCH) { s_b1[v] = b1[v]; s_w2[v] = w2[v]; }
+  }
   __syncthreads();
   if (tid >= nrow) return;
   const long idx = idx0 + tid;
   const int b = (int)(idx / HW), a = (int)(idx - (long)b * HW);
   const int ay = a / W, ax = a - ay * W;
-  const T* bp = s_box + tid * boxLs;
+  const T* bp = vec ? box + idx * boxCs : s_box + tid * boxLs;
   float stat[20], dist[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -84,11 +86,17 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int 
   float q = 1.f;
   if (w1) {
     float o = b2[0];
+#pragma unroll 4
     for (int j = 0; j < hid; ++j) {
-      float hsum = b1[j];
+      const f32x4* wr = reinterpret_cast<const f32x4*>(s_w1 + j * 20);
+      float hsum = s_b1[j];
 #pragma unroll
-      for (int i = 0; i < 20; ++i) hsum += w1[j * 20 + i] * stat[i];
-      o += w2[j] * fmaxf(hsum, 0.f);
+      for (int i4 = 0; i4 < 5; ++i4) {
+        const f32x4 w4 = wr[i4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hsum += w4[i] * stat[i4 * 4 + i];
+      }
+      o += s_w2[j] * fmaxf(hsum, 0.f);
     }
     q = fminf(fmaxf(ey_sigmoid(o), 1e-6f), 1.f - 1e-6f);
   }
@@ -129,8 +137,8 @@ extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stri
   EY_CHECK(!q_w1 || (q_b1 && q_w2 && q_b2 && q_hidden > 0), "head_decode: incomplete quality head");
   const int es = dtype == EY_F16 ? 2 : 4;
   const int vec = nc % 8 == 0 && (box_cstride * es) % 16 == 0 && (cls_cstride * es) % 16 == 0 && ey_aligned(box, 16) && ey_aligned(cls, 16);
-  const int boxLs = hd_pad(64, es), clsLs = hd_pad(nc, es);
-  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es;
+  const int boxLs = vec ? 0 : hd_pad(64, es), clsLs = hd_pad(nc, es);
+  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es + (q_w1 ? (size_t)q_hidden * 22 * 4 : 0);
   EY_CHECK(lds <= 160 * 1024, "head_decode: nc=%d needs %zu B of LDS", nc, lds);
   const long total = (long)B * H * W;
   dim3 grid((unsigned)((total + HD_ANCH - 1) / HD_ANCH));
