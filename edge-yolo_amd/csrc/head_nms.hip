@@ -188,6 +188,22 @@ __global__ __launch_bounds__(256) void nms_score_kernel(int nc, int A, const flo
   keys[(long)b * P + a] = key;
 }
 
+// multi_label (validation-mode) keys: one candidate per (anchor, class) pair with score > conf, enumerated anchor-major
+// like `torch.where(cls > conf_thres)` (ops.py:270-272): key = (score_bits << 32) | (0xFFFFFFFF - (a*nc + c)).
+__global__ __launch_bounds__(256) void nms_score_ml_kernel(int nc, int A, const float* __restrict__ pred, float conf_thres,
+                                                           const uint8_t* __restrict__ class_mask, unsigned long long* __restrict__ keys, long P) {
+  const int b = blockIdx.y;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // = c*Apad + a  (a fastest: coalesced reads)
+  const int Apad = (A + 255) / 256 * 256;
+  const int c = (int)(idx / Apad), a = (int)(idx - (long)c * Apad);
+  if (c >= nc || a >= A) return;
+  const float v = pred[(long)b * (4 + nc) * A + (long)(4 + c) * A + a];
+  unsigned long long key = 0ull;
+  if (v > conf_thres && (!class_mask || class_mask[c]))
+    key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(a * nc + c));
+  keys[(long)b * P + (long)a * nc + c] = key;
+}
+
 struct KeptBox { float x1, y1, x2, y2, area; };
 
 // torchvision CPU kernel arithmetic, op by op, round-to-nearest, no FMA contraction.  The early-out is exact: with
@@ -247,7 +263,7 @@ __device__ __forceinline__ void nms_block_suffix_scan(unsigned* h) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, int P, const float* __restrict__ pred, float iou_thres, int max_det,
+__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, int multi_label, const float* __restrict__ pred, float iou_thres, int max_det,
                                                                  int max_nms, float max_wh, int agnostic,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long* keys = gkeys + (long)b * P;
   const float* pb = pred + (long)b * (4 + nc) * A;
-  const int* cid = cls_id + (long)b * P;
+  const int* cid = cls_id + (long)b * P;  // (single-label only)
 
   // radix-descent state (wave-uniform, identical in every thread)
   const int SHIFT[6] = {51, 39, 27, 15, 3, 0};
@@ -278,7 +294,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     if (need_hist) {
       for (int i = tid; i < 4096; i += 1024) S.hist[i] = 0u;
       __syncthreads();
-      for (int i = tid; i < P; i += 1024) {
+      for (long i = tid; i < P; i += 1024) {
         const unsigned long long k = keys[i];
         if (k != 0ull && (k & above_mask) == prefix[level]) atomicAdd(&S.hist[(unsigned)(k >> sh) & (nb - 1)], 1u);
       }
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     // ---- gather the chunk (unordered), then sort it
     if (tid == 0) S.cnt = 0;
     __syncthreads();
-    for (int i = tid; i < P; i += 1024) {
+    for (long i = tid; i < P; i += 1024) {
       const unsigned long long k = keys[i];
       if (k != 0ull && (k & above_mask) == prefix[level]) {
         const int dgt = (int)((unsigned)(k >> sh) & (nb - 1));
@@ -361,10 +377,11 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
         const unsigned long long key = S.chunk[i];
         a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         conf = __uint_as_float((unsigned)(key >> 32));
+        if (multi_label) { ci = a % nc; a = a / nc; }
         const float cx = pb[a], cy = pb[(long)A + a], w = pb[2L * A + a], h = pb[3L * A + a];
         const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432 (x/2 is exact)
         ux1 = __fsub_rn(cx, hw); uy1 = __fsub_rn(cy, hh); ux2 = __fadd_rn(cx, hw); uy2 = __fadd_rn(cy, hh);
-        ci = cid[a];
+        if (!multi_label) ci = cid[a];
         const float off = agnostic ? 0.f : __fmul_rn((float)ci, max_wh);  // ops.py:289
         x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
         area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
@@ -442,28 +459,40 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
 static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array length per image (padded for the score kernel grid)
 
 extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4); }  // keys + class ids
+extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size_t)B * (((size_t)A * nc + 255) / 256 * 256) * 8; }
 
 extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
-                      const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
+                      int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
                       ey_stream_t stream) {
   EY_CHECK(pred && out_boxes && out_count && workspace, "nms: null pointer");
   EY_CHECK(B > 0 && nc > 0 && A > 0, "nms: bad extent");
   EY_CHECK(conf_thres >= 0.f && conf_thres <= 1.f, "nms: Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", conf_thres);
   EY_CHECK(iou_thres >= 0.f && iou_thres <= 1.f, "nms: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
   EY_CHECK(max_det > 0 && max_det <= 4096 && max_nms > 0, "nms: max_det=%d (1..4096) max_nms=%d", max_det, max_nms);
-  EY_CHECK(workspace_bytes >= ey_nms_workspace_bytes(B, A) && ey_aligned(workspace, 8), "nms: workspace too small");
-  const int P = nms_pow2(A);
+  multi_label = multi_label && nc > 1;  // ops.py:240
+  EY_CHECK(workspace_bytes >= (multi_label ? ey_nms_workspace_bytes_ml(B, nc, A) : ey_nms_workspace_bytes(B, A)) && ey_aligned(workspace, 8),
+           "nms: workspace too small");
+  EY_CHECK(!multi_label || (long)A * nc < (1L << 31), "nms: A*nc too large");
   hipStream_t st = (hipStream_t)stream;
   unsigned long long* keys = (unsigned long long*)workspace;
-  int* cls_id = (int*)(keys + (size_t)B * P);
-  hipLaunchKernelGGL(nms_score_kernel, dim3(P / 256, B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask,
-                     keys, cls_id, P);
+  long P;
+  int* cls_id = nullptr;
+  if (multi_label) {
+    P = ((long)A * nc + 255) / 256 * 256;
+    const int Apad = (A + 255) / 256 * 256;
+    hipMemsetAsync(keys, 0, (size_t)B * P * 8, st);  // (tail padding; every real slot is written by the kernel)
+    hipLaunchKernelGGL(nms_score_ml_kernel, dim3((unsigned)((long)Apad * nc / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, P);
+  } else {
+    P = nms_pow2(A);
+    cls_id = (int*)(keys + (size_t)B * P);
+    hipLaunchKernelGGL(nms_score_kernel, dim3((unsigned)(P / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, cls_id, (int)P);
+  }
   EY_LAUNCH_CHECK("ey_nms(score)");
   const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox);
   EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
-  hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, pred, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id,
+  hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, multi_label, pred, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id,
                      out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;

@@ -370,20 +370,21 @@ def head_decode(box, cls, stride, q, pred, a_off):
                                        qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
 
 
-def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None):
+def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None, multi_label=False):
     """pred fp32 (B,4+nc,A) contiguous -> (boxes (B,max_det,6) fp32, count (B,) int32, index (B,max_det) int32)."""
     L.require_device(pred, "nms")
     if pred.dtype != torch.float32 or not pred.is_contiguous():
         raise ValueError("nms: pred must be a contiguous float32 (B,4+nc,A) tensor")
     B, no, A = pred.shape
     dev = pred.device
+    multi_label = bool(multi_label) and no - 4 > 1  # reference ops.py:240
     boxes = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=torch.int32, device=dev)
     index = torch.empty((B, max_det), dtype=torch.int32, device=dev)
-    nbytes = L.lib().ey_nms_workspace_bytes(B, A)
+    nbytes = L.lib().ey_nms_workspace_bytes_ml(B, no - 4, A) if multi_label else L.lib().ey_nms_workspace_bytes(B, A)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with _tr("nms(score+sort_greedy)", _nb(pred, boxes)):
-        L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)),
+        L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)), int(bool(multi_label)),
                                class_mask.data_ptr() if class_mask is not None else None, boxes.data_ptr(), count.data_ptr(), index.data_ptr(),
                                ws.data_ptr(), nbytes, L.stream()), "ey_nms")
     return boxes, count, index

@@ -46,7 +46,8 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xyw
     return clip_boxes(boxes, img0_shape)
 
 
-def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, nc=0, max_nms=30000, max_wh=7680):
+def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, nc=0, max_nms=30000, max_wh=7680,
+               multi_label=False):
     """Batched NMS on the device, fixed-size outputs (graph-capturable): returns (boxes (B,max_det,6), count (B,),
     index (B,max_det)).  `prediction` is (B,4+nc,A); fp16 input is promoted to fp32 first (the reference promotes inside
     NMS, ops.py:275; this build keeps head outputs in fp32 end to end)."""
@@ -64,20 +65,21 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
         mask = torch.zeros(nc, dtype=torch.uint8)
         mask[torch.as_tensor(list(classes), dtype=torch.long)] = 1
         mask = mask.to(p.device)
-    return _ops.nms(p, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, mask)
+    return _ops.nms(p, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, mask, multi_label)
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False, labels=(),
                         max_det=300, nc=0, max_time_img=0.05, max_nms=30000, max_wh=7680, in_place=True, rotated=False):
     """Reference signature (ops.py:167-183); returns a list of (n_i, 6) tensors [x1,y1,x2,y2,conf,cls].
+    multi_label=True is the validation-mode variant (one candidate per (anchor, class) above conf, ops.py:270-272).
     Differences, all deliberate: no wall-clock abort (:238,:312-314 make the reference output timing dependent);
-    the input tensor is not rewritten to xyxy in place; multi_label / labels / rotated are not built and raise."""
-    if multi_label or (labels and len(labels)) or rotated:
-        raise NotImplementedError("multi_label / autolabel / rotated NMS variants are not part of the built predict path")
+    the input tensor is not rewritten to xyxy in place; labels (autolabel) / rotated are not built and raise."""
+    if (labels and len(labels)) or rotated:
+        raise NotImplementedError("autolabel / rotated NMS variants are not part of the built path")
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
     if prediction.shape[-1] == 6:
         raise NotImplementedError("end-to-end (B,N,6) predictions need no NMS and are outside the built path")
-    boxes, count, _ = nms_device(prediction, conf_thres, iou_thres, classes, agnostic, max_det, nc, max_nms, max_wh)
+    boxes, count, _ = nms_device(prediction, conf_thres, iou_thres, classes, agnostic, max_det, nc, max_nms, max_wh, multi_label)
     n = count.tolist()  # one D2H sync for the whole batch
     return [boxes[i, : n[i]] for i in range(len(n))]

@@ -158,14 +158,17 @@ int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const v
                    const void* cls, int cls_cstride, const float* q_w1, const float* q_b1, const float* q_w2,
                    const float* q_b2, int q_hidden, float* pred, int A_total, int a_off, ey_stream_t stream);
 
-/* ---- K11: batched per-image NMS (non_max_suppression single-label path, utils/ops.py:230-316, and the
- * torchvision.ops.nms it calls at :296).  pred fp32 [B,4+nc,A] (xywh + scores), NOT modified.
+/* ---- K11: batched per-image NMS (non_max_suppression, utils/ops.py:230-316, and the torchvision.ops.nms it calls
+ * at :296).  multi_label=0: best class per anchor (predict, ops.py:273-275); multi_label=1: one candidate per
+ * (anchor, class) pair above conf (validation, ops.py:270-272; needs the _ml workspace).
+ * pred fp32 [B,4+nc,A] (xywh + scores), NOT modified.
  * out_boxes fp32 [B,max_det,6] = x1,y1,x2,y2,conf,cls in kept (descending score) order; out_count int32 [B];
  * out_index int32 [B,max_det] = anchor index of each kept row (may be NULL); class_mask uint8 [nc] or NULL
  * (the `classes=` filter).  workspace: ey_nms_workspace_bytes(B, A) bytes. */
 size_t ey_nms_workspace_bytes(int B, int A);
+size_t ey_nms_workspace_bytes_ml(int B, int nc, int A);
 int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms,
-           float max_wh, int agnostic, const uint8_t* class_mask, float* out_boxes, int32_t* out_count,
+           float max_wh, int agnostic, int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count,
            int32_t* out_index, void* workspace, size_t workspace_bytes, ey_stream_t stream);
 
 #ifdef __cplusplus

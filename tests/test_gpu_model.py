@@ -115,3 +115,29 @@ def test_predict_surface_and_graph(E):
         assert a.boxes.xyxy.shape[1] == 4 and a.boxes.conf.ndim == 1 and a.boxes.cls.ndim == 1
     with pytest.raises(RuntimeError):
         model.predict(x, device="cpu")
+
+
+@pytest.mark.parametrize("name,hw", [("yolo11s-test.yaml", 128), ("yolo11s.yaml", 128), ("yolo11m-test.yaml", 64)])
+def test_fp32_other_scales_vs_oracle(E, cfg_dir, name, hw):
+    """Wider models: other channel counts exercise other tile variants (NT, chunked weights, 4-head attention)."""
+    m, sd = _build(E, name, torch.float32)
+    x = synth.synth_images(1, hw, hw)
+    want, _ = om.OracleModel(os.path.join(cfg_dir, name), sd)(x)
+    y, _ = m(x.cuda())
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-3)
+
+
+def test_1280_config5_shapes(E, cfg_dir):
+    """BASELINE config 5 geometry (1280x1280: A=33600 anchors, N=1600 attention tokens): fp32 parity vs the oracle on one image
+    and NMS rows bit-exact on that output."""
+    name = "yolo11n-test.yaml"
+    m, sd = _build(E, name, torch.float32)
+    x = synth.synth_images(1, 1280, 1280)
+    want, _ = om.OracleModel(os.path.join(cfg_dir, name), sd)(x)
+    y, _ = m(x.cuda())
+    assert tuple(y.shape) == (1, 84, 33600)
+    np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=2e-4, atol=4e-3)
+    from edge_yolo_amd.utils import ops
+    det = ops.non_max_suppression(y, 0.25, 0.7)[0].cpu().numpy()
+    ref = onms.non_max_suppression(y.cpu().numpy(), 0.25, 0.7)[0]
+    np.testing.assert_array_equal(det, ref)

@@ -23,6 +23,7 @@ def _preds(g):
     return {
         "sparse": synth.synth_pred(2, 80, 8400, seed=2), "dense": synth.synth_pred(1, 80, 8400, seed=3, dense=True),
         "nc10": synth.synth_pred(1, 10, 336, seed=5, imgsz=128, dense=True),
+        "val_multilabel": synth.synth_pred(1, 80, 2100, seed=4, dense=True),
         "none_pass": synth.synth_pred(2, 80, 336, seed=6) * torch.tensor(1e-3), "hand": torch.tensor(g["hand_pred"]),
     }
 
@@ -32,8 +33,6 @@ def test_golden_cases(ops, golden_dir):
     meta = json.load(open(os.path.join(golden_dir, "nms_cases.json")))
     preds = _preds(g)
     for tag, m in meta.items():
-        if m["kw"].get("multi_label"):
-            continue  # val-mode NMS is a SURVEY §8(f) "next" row; the entry point raises NotImplementedError for it
         base = "sparse" if tag.startswith("sparse") else "hand" if tag.startswith("hand") else tag
         out = ops.non_max_suppression(preds[base].cuda(), **m["kw"])
         assert [int(o.shape[0]) for o in out] == m["n"], tag
@@ -71,9 +70,19 @@ def test_score_ties_and_pow2_edge(ops):
     assert out.shape[0] == A
 
 
+@pytest.mark.parametrize("B,nc,A,conf,max_det", [(2, 80, 8400, 0.001, 300), (2, 3, 500, 0.05, 100), (1, 1, 300, 0.01, 50)])
+def test_multi_label_vs_oracle(ops, B, nc, A, conf, max_det):
+    """validation-mode NMS (reference val.py:92-102: conf 0.001, multi_label=True): up to A*nc candidates, max_nms cap 30000."""
+    pred = synth.synth_pred(B, nc, A, seed=21, dense=True)
+    want = onms.non_max_suppression(pred.numpy(), conf, 0.7, multi_label=True, max_det=max_det)
+    out = ops.non_max_suppression(pred.cuda(), conf, 0.7, multi_label=True, max_det=max_det)
+    for a, b in zip(out, want):
+        np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
 def test_argument_errors(ops):
     pred = synth.synth_pred(1, 4, 64, seed=1).cuda()
     with pytest.raises(AssertionError):
         ops.non_max_suppression(pred, conf_thres=1.5)
     with pytest.raises(NotImplementedError):
-        ops.non_max_suppression(pred, multi_label=True)
+        ops.non_max_suppression(pred, rotated=True)

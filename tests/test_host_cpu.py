@@ -140,7 +140,7 @@ def test_no_cpu_fallback_anywhere():
     with pytest.raises(NotImplementedError):
         m.train()
     with pytest.raises(NotImplementedError):
-        uops.non_max_suppression(torch.zeros(1, 84, 100), multi_label=True)
+        uops.non_max_suppression(torch.zeros(1, 84, 100), rotated=True)
 
 
 def test_product_does_not_import_oracle():
