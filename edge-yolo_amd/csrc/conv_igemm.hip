@@ -316,6 +316,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4 (&acc)
   T* yp = (T*)p.y + (long)grp * p.yG + m * p.yCs + ch0;
   const T* rp = p.res ? (const T*)p.res + (long)grp * p.yG + m * p.resCs + ch0 : nullptr;
   if (p.vec_store && full) {
+    if constexpr (sizeof(T) == 2 && NT % 2 == 0) {
+      if (p.vec_store > 1) {  // 16-byte stores: a lane's 4*NT channels are contiguous (half the store instructions / sectors touched)
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+          if (rp) {
+            Vec8<T> rr;
+            rr.load(rp + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * q + j] += rr.get(j);
+          }
+          Vec8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.set(j, v[8 * q + j]);
+          o.store(yp + 8 * q);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
       if (rp) {
@@ -997,6 +1015,9 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   p.vec_store = d->Cout % 4 == 0 && (d->y_cstride * es) % va == 0 && ey_aligned(d->y, va) && (d->y_gstride * es) % va == 0 &&
                 (!d->res || ((d->res_cstride * es) % va == 0 && ey_aligned(d->res, va))) &&
                 (!d->addz || ((d->addz_cstride * es) % va == 0 && ey_aligned(d->addz, va))) && (!d->bias || ey_aligned(d->bias, 16));
+  if (p.vec_store && (d->y_cstride * es) % 16 == 0 && ey_aligned(d->y, 16) && (d->y_gstride * es) % 16 == 0 &&
+      (!d->res || ((d->res_cstride * es) % 16 == 0 && ey_aligned(d->res, 16))))
+    p.vec_store = 2;  // 16-byte epilogue accesses allowed
   hipStream_t st = (hipStream_t)stream;
   const int sm = d->dtype == EY_F16 ? dispatch_small<f16>(p, ngroup, st) : dispatch_small<float>(p, ngroup, st);
   if (sm != 0) return sm < 0 ? sm : EY_OK;

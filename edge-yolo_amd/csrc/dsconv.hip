@@ -158,7 +158,21 @@ __global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
       }
       T* yp = (T*)p.y + m * p.yCs + ch0;
       const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
-      if (p.vec_store && full) {
+      if (p.vec_store > 1 && full && sizeof(T) == 2 && NT % 2 == 0) {  // 16-byte accesses (see conv_igemm.hip epilogue)
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+          if (rp) {
+            Vec8<T> rr;
+            rr.load(rp + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * q + j] += rr.get(j);
+          }
+          Vec8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.set(j, v[8 * q + j]);
+          o.store(yp + 8 * q);
+        }
+      } else if (p.vec_store && full) {
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
           float o[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
@@ -268,6 +282,7 @@ extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int 
   p.ntile = (long)B * p.tilesX * p.tilesY;
   const int va = 4 * es;
   p.vec_store = Cout % 4 == 0 && (y_cstride * es) % va == 0 && ey_aligned(y, va) && (!res || ((res_cstride * es) % va == 0 && ey_aligned(res, va)));
+  if (p.vec_store && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16) && (!res || ((res_cstride * es) % 16 == 0 && ey_aligned(res, 16)))) p.vec_store = 2;
   hipStream_t st = (hipStream_t)stream;
   return dtype == EY_F16 ? ds_launch_k<f16>(p, k, st) : ds_launch_k<float>(p, k, st);
 }
