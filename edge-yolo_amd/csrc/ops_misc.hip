@@ -47,53 +47,99 @@ extern "C" int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream
 }
 
 // ============================================================================ stem: NCHW image -> NHWC, 3x3 s2
-// One thread = one output pixel x 16 output channels.  Weights are wave-uniform (scalar loads); the 27 input
-// taps are read once per thread from the planar image (adjacent threads read adjacent columns).
+// One thread = TWO horizontally adjacent output pixels x 16 output channels: the 5 x 3 input window per channel is
+// read once for both (range-checked buffer loads: the zero padding and the right/bottom edges need no branches; f16
+// columns are fetched as aligned pairs), the 2 x 16 results leave as 64 contiguous bytes.  Weights are wave-uniform.
+template <typename TI> struct StemLoad;
+template <> struct StemLoad<f16> {
+  // columns (c0-1, c0, c0+1, c0+2, c0+3) of one image row; c0 even
+  static __device__ __forceinline__ void row5(__amdgpu_buffer_rsrc_t r, long rowbase, int c0, int W, bool rowok, float (&o)[5]) {
+    const unsigned b0 = (unsigned)((rowbase + c0) * 2);
+    const unsigned short s = __builtin_amdgcn_raw_buffer_load_b16(r, (rowok && c0 >= 1) ? b0 - 2u : EY_OOB, 0, 0);
+    const unsigned p0 = __builtin_amdgcn_raw_buffer_load_b32(r, (rowok && c0 + 1 < W) ? b0 : EY_OOB, 0, 0);
+    const unsigned p1 = __builtin_amdgcn_raw_buffer_load_b32(r, (rowok && c0 + 3 < W) ? b0 + 4u : EY_OOB, 0, 0);
+    o[0] = (float)__builtin_bit_cast(f16, s);
+    o[1] = (float)__builtin_bit_cast(f16, (unsigned short)(p0 & 0xFFFFu));
+    o[2] = (float)__builtin_bit_cast(f16, (unsigned short)(p0 >> 16));
+    o[3] = (float)__builtin_bit_cast(f16, (unsigned short)(p1 & 0xFFFFu));
+    o[4] = (float)__builtin_bit_cast(f16, (unsigned short)(p1 >> 16));
+  }
+};
+template <> struct StemLoad<float> {
+  static __device__ __forceinline__ void row5(__amdgpu_buffer_rsrc_t r, long rowbase, int c0, int W, bool rowok, float (&o)[5]) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = c0 - 1 + i;
+      o[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (rowok && c >= 0 && c < W) ? (unsigned)((rowbase + c) * 4) : EY_OOB, 0, 0));
+    }
+  }
+};
+
 template <typename TI, typename TO, int CIN>
-__global__ __launch_bounds__(256) void stem_kernel(int B, int H, int W, int Ho, int Wo, int Cout, int act, const TI* __restrict__ x,
+__global__ __launch_bounds__(256) void stem_kernel(int B, int H, int W, int Ho, int Wo, int Cout, int act, const TI* __restrict__ x, unsigned xbytes,
                                                    const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ y, int yCs) {
-  const long M = (long)B * Ho * Wo;
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+  const int Wp = (Wo + 1) >> 1;  // pixel pairs per output row
+  const long npair = (long)B * Ho * Wp;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= npair) return;
   const int co0 = blockIdx.y * 16;
-  const int ox = (int)(m % Wo);
-  const long t = m / Wo;
-  const int oy = (int)(t % Ho);
-  const int b = (int)(t / Ho);
-  float in[CIN * 9];
+  const int px = (int)(t % Wp);
+  const long tt = t / Wp;
+  const int oy = (int)(tt % Ho), b = (int)(tt / Ho);
+  const int ox = px * 2, c0 = ox * 2;  // input column of tap kx=1 of the first pixel
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc(x, xbytes);
+  float in[CIN][3][5];
 #pragma unroll
   for (int c = 0; c < CIN; ++c)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        in[(c * 3 + ky) * 3 + kx] = ok ? to_f(x[(((long)b * CIN + c) * H + iy) * W + ix]) : 0.f;
-      }
-  float acc[16];
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * 2 - 1 + ky;
+      StemLoad<TI>::row5(rs, (((long)b * CIN + c) * H + iy) * W, c0, W, iy >= 0 && iy < H, in[c][ky]);
+    }
+  float a0[16], a1[16];
 #pragma unroll
   for (int o = 0; o < 16; ++o) {
-    float a = bias ? bias[co0 + o] : 0.f;
+    float s0 = bias ? bias[co0 + o] : 0.f, s1 = s0;
     const float* wo = w + (long)(co0 + o) * CIN * 9;
 #pragma unroll
-    for (int i = 0; i < CIN * 9; ++i) a += in[i] * wo[i];
-    acc[o] = ey_act(a, act);
-  }
-  TO* yp = y + m * yCs + co0;
-  Vec8<TO> v0, v1;
+    for (int c = 0; c < CIN; ++c)
 #pragma unroll
-  for (int o = 0; o < 8; ++o) { v0.set(o, acc[o]); v1.set(o, acc[8 + o]); }
-  v0.store(yp);
-  v1.store(yp + 8);
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const float wv = wo[(c * 3 + ky) * 3 + kx];
+          s0 += in[c][ky][kx] * wv;
+          s1 += in[c][ky][kx + 2] * wv;
+        }
+    a0[o] = ey_act(s0, act);
+    a1[o] = ey_act(s1, act);
+  }
+  TO* yp = y + (((long)b * Ho + oy) * Wo + ox) * yCs + co0;
+  Vec8<TO> v;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) v.set(o, a0[o]);
+  v.store(yp);
+#pragma unroll
+  for (int o = 0; o < 8; ++o) v.set(o, a0[8 + o]);
+  v.store(yp + 8);
+  if (ox + 1 < Wo) {
+#pragma unroll
+    for (int o = 0; o < 8; ++o) v.set(o, a1[o]);
+    v.store(yp + yCs);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) v.set(o, a1[8 + o]);
+    v.store(yp + yCs + 8);
+  }
 }
 
 template <typename TI, typename TO>
 static int stem_launch(int B, int Cin, int H, int W, int Cout, int act, const void* x, const float* w, const float* bias, void* y, int yCs, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long M = (long)B * Ho * Wo;
-  dim3 grid((unsigned)((M + 255) / 256), Cout / 16);
-#define STEM(CI) hipLaunchKernelGGL((stem_kernel<TI, TO, CI>), grid, dim3(256), 0, st, B, H, W, Ho, Wo, Cout, act, (const TI*)x, w, bias, (TO*)y, yCs)
+  const long npair = (long)B * Ho * ((Wo + 1) / 2);
+  const long xbytes = (long)B * Cin * H * W * (long)sizeof(TI);
+  if (xbytes >= (1L << 31)) return ey_set_error(EY_EUNSUPPORTED, "stem: input batch larger than 2 GiB");
+  dim3 grid((unsigned)((npair + 255) / 256), Cout / 16);
+#define STEM(CI) hipLaunchKernelGGL((stem_kernel<TI, TO, CI>), grid, dim3(256), 0, st, B, H, W, Ho, Wo, Cout, act, (const TI*)x, (unsigned)xbytes, w, bias, (TO*)y, yCs)
   switch (Cin) {
     case 1: STEM(1); break;
     case 2: STEM(2); break;
@@ -112,6 +158,7 @@ extern "C" int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int
   EY_CHECK(B > 0 && H > 0 && W > 0, "stem: bad extent");
   const int es = y_dtype == EY_F16 ? 2 : 4;
   EY_CHECK(y_cstride >= Cout && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16), "stem: output view not 16-byte aligned");
+  EY_CHECK(x_dtype != EY_F16 || (W % 2 == 0 && ey_aligned(x, 4)), "stem: f16 images need an even width (column pairs are fetched as 32-bit words)");
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == EY_F16 && y_dtype == EY_F16) return stem_launch<f16, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
   if (x_dtype == EY_F32 && y_dtype == EY_F16) return stem_launch<float, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
