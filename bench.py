@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=16)
+    ap.add_argument("--no-pipeline", action="store_true", help="one graph per batch, no overlap of NMS(i) with forward(i+1)")
     return ap.parse_args()
 
 
@@ -94,7 +95,7 @@ def main():
     dtype = torch.float16 if a.dtype == "f16" else torch.float32
     conf, iou, max_det = 0.25, 0.7, 300
 
-    from edge_yolo_amd.engine.predictor import GraphRunner
+    from edge_yolo_amd.engine.predictor import GraphRunner, PipelinedRunner
     from edge_yolo_amd.utils import ops
     from edge_yolo_amd import dist as eydist
     model, sd = build_model(a.model, dtype, dev)
@@ -107,18 +108,39 @@ def main():
         boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
         return boxes, count
 
-    runner = GraphRunner(device_step)
-    images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
     gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if world > 1 else None
+    if a.no_pipeline:
+        runner = GraphRunner(device_step)
+        images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
 
-    def step():
-        boxes, count = runner(images)
-        if gather is not None:
-            gather(boxes, count)
-        return boxes, count
+        def step():
+            boxes, count = runner(images)
+            if gather is not None:
+                gather(boxes, count)
+            return boxes, count
+
+        def drain():
+            pass
+    else:
+        # stage 1 = network forward, stage 2 = NMS; NMS of batch i overlaps the forward of batch i+1 (both always run in full)
+        pipe = PipelinedRunner(lambda im: model(im)[0], lambda pred: ops.nms_device(pred, conf, iou, max_det=max_det)[:2], images)
+        for j in range(2):
+            pipe.static_input(j).copy_(images)  # both buffer sets hold the resident batch: no per-step copy
+
+        def step():
+            j = pipe.submit()
+            boxes, count = pipe.outputs(j)
+            if gather is not None:
+                with torch.cuda.stream(pipe.sp):  # the gather follows this batch's NMS on the post-processing stream
+                    gather(boxes, count)
+            return boxes, count
+
+        def drain():
+            pipe.wait()
 
     for _ in range(a.warmup):
         step()
+    drain()
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
@@ -128,6 +150,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         boxes, count = step()
+    drain()
     if gather is not None:
         gather.wait()
     torch.cuda.synchronize()
@@ -152,10 +175,12 @@ def main():
             "config": {"workload": f"{a.model} (EdgeLine-YOLO scale n, nc=80) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
                                    f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
-                       "global_batch": a.batch * world, "imgsz": a.imgsz, "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
+                       "global_batch": a.batch * world, "imgsz": a.imgsz,
+                       "pipeline": "single graph per batch" if a.no_pipeline else "forward(i+1) || NMS(i) on two HIP streams, 2 graphs per batch", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:
         from edge_yolo_amd import profiling
+        torch.cuda.synchronize()
         out["roofline"] = profiling.dominant_kernel_roofline(lambda: device_step(images), steps=min(a.steps, 10), hbm_peak_gbs=HBM_PEAK_GBS,
                                                              mfma_peak_tflops=MFMA_F16_PEAK_TFLOPS)
     if world > 1:

@@ -71,6 +71,72 @@ class GraphRunner:
         return self.graphs[(tuple(like.shape), like.dtype, like.device)][1]
 
 
+class PipelinedRunner:
+    """Two-stage software pipeline over consecutive batches: stage 1 (network forward -> pred) of batch i+1 runs on one HIP
+    stream while stage 2 (NMS: one latency-bound workgroup per image, ~1/8 of the CUs) of batch i runs on another.  Each
+    stage is a captured hipGraph; two buffer sets alternate, so nothing is copied between the stages.  Every batch still
+    goes through both stages in full — only their placement in time overlaps (throughput mode; one batch of extra latency).
+    """
+
+    def __init__(self, forward_fn, post_fn, example, warmup=2):
+        dev = example.device
+        self.dev = dev
+        self.sf, self.sp = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.sets = []
+        cur = torch.cuda.current_stream(dev)
+        for _ in range(2):
+            static_in = example.clone()
+            self.sf.wait_stream(cur)
+            with torch.cuda.stream(self.sf):
+                for _ in range(warmup):
+                    mid = forward_fn(static_in)
+                    out = post_fn(mid)
+            cur.wait_stream(self.sf)
+            torch.cuda.synchronize(dev)
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                mid = forward_fn(static_in)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                out = post_fn(mid)
+            self.sets.append(dict(x=static_in, g1=g1, g2=g2, out=out, fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event()))
+        self.i = 0
+        for st in self.sets:  # events start in the signalled state
+            st["fwd_done"].record(cur)
+            st["post_done"].record(cur)
+
+    def static_input(self, j=None):
+        return self.sets[self.i & 1 if j is None else j]["x"]
+
+    def submit(self, x=None):
+        """Enqueue one batch (x=None: the batch already sits in static_input()).  Returns the buffer-set index; its outputs
+        are valid after `wait(j)` / a device synchronise."""
+        j = self.i & 1
+        self.i += 1
+        st = self.sets[j]
+        cur = torch.cuda.current_stream(self.dev)
+        self.sf.wait_stream(cur)
+        with torch.cuda.stream(self.sf):
+            self.sf.wait_event(st["post_done"])  # NMS of the batch that used this buffer set two submits ago
+            if x is not None and x.data_ptr() != st["x"].data_ptr():
+                st["x"].copy_(x, non_blocking=True)
+            st["g1"].replay()
+            st["fwd_done"].record(self.sf)
+        with torch.cuda.stream(self.sp):
+            self.sp.wait_event(st["fwd_done"])
+            st["g2"].replay()
+            st["post_done"].record(self.sp)
+        return j
+
+    def outputs(self, j):
+        return self.sets[j]["out"]
+
+    def wait(self, j=None):
+        cur = torch.cuda.current_stream(self.dev)
+        for k in ([j] if j is not None else [0, 1]):
+            cur.wait_event(self.sets[k]["post_done"])
+
+
 class DetectionPredictor:
     def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True):
         self.model, self.device, self.half = model, device, half

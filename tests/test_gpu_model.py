@@ -141,3 +141,40 @@ def test_1280_config5_shapes(E, cfg_dir):
     det = ops.non_max_suppression(y, 0.25, 0.7)[0].cpu().numpy()
     ref = onms.non_max_suppression(y.cpu().numpy(), 0.25, 0.7)[0]
     np.testing.assert_array_equal(det, ref)
+
+
+def test_pipelined_runner_matches_single_graph(E):
+    """The two-stream pipeline (forward(i+1) || NMS(i)) must return, per batch, exactly what the single-graph runner returns."""
+    from edge_yolo_amd.engine.predictor import GraphRunner, PipelinedRunner
+    from edge_yolo_amd.utils import ops
+    m, _ = _build(E, "yolo11n-test.yaml", torch.float16)
+    xs = [synth.synth_images(2, 128, 128, seed=s).cuda().half() for s in range(5)]
+
+    def fwd(im):
+        return m(im)[0]
+
+    def post(pred):
+        return ops.nms_device(pred, 0.25, 0.7, max_det=50)[:2]
+
+    single = GraphRunner(lambda im: post(fwd(im)))
+    want = []
+    for x in xs:
+        b, c = single(x)
+        want.append((b.clone(), c.clone()))
+    pipe = PipelinedRunner(fwd, post, xs[0])
+    got = []
+    for x in xs:
+        j = pipe.submit(x)
+        pipe.wait(j)
+        torch.cuda.synchronize()
+        b, c = pipe.outputs(j)
+        got.append((b.clone(), c.clone()))
+    # and back-to-back without waiting in between (the overlapped regime): last two results must still be right
+    js = [pipe.submit(x) for x in xs[-2:]]
+    pipe.wait()
+    torch.cuda.synchronize()
+    for (wb, wc), (gb, gc) in zip(want, got):
+        assert torch.equal(wc, gc) and torch.equal(wb, gb)
+    for j, (wb, wc) in zip(js, want[-2:]):
+        b, c = pipe.outputs(j)
+        assert torch.equal(wc, c) and torch.equal(wb, b)
