@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
         ("w", C.c_void_p), ("bias", C.c_void_p), ("y", C.c_void_p), ("y_cstride", C.c_int32),
         ("res", C.c_void_p), ("res_cstride", C.c_int32), ("out_scale", C.c_float),
         ("addz", C.c_void_p), ("addz_cstride", C.c_int32), ("addz_H", C.c_int32), ("addz_W", C.c_int32), ("ngroup", C.c_int32),
-        ("src_gstride", C.c_int64), ("y_gstride", C.c_int64),
+        ("src_gstride", C.c_int64), ("y_gstride", C.c_int64), ("w_gstride", C.c_int64), ("w_gmax", C.c_int32),
     ]
 
 

@@ -29,6 +29,8 @@ struct ConvP {
   int addzCs, Hz, Wz;
   float zsy, zsx;  // input/output size ratios of the bilinear resize
   long srcG, yG;
+  long wG;       // weight-set stride (elements) and highest set index: group g uses set min(g, wGmax)
+  int wGmax;
   int Kpad;      // packed row length (elements)
   int nchunks;   // number of (tap, source, <=128-channel) K chunks
   unsigned srcBytes[2];  // byte extent of each source view (buffer-load range check)
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
 
-  const T* wg = (const T*)p.w + (long)n_base * p.Kpad;  // this block's rows of the packed weights
+  const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad;  // this block's rows of the packed weights
 
   // chunk iterator (wave-uniform)
   int ky = 0, kx = 0, src = 0, c0 = 0, kofs = 0;
@@ -209,9 +211,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mt][nt][j];
     if (p.bias) {
+      const float* pbias = p.bias + min(grp, p.wGmax) * p.Cout;
 #pragma unroll
       for (int i = 0; i < 4 * NT; ++i)
-        if (ch0 + i < p.Cout) v[i] += p.bias[ch0 + i];
+        if (ch0 + i < p.Cout) v[i] += pbias[ch0 + i];
     }
     if (p.addz) {
       // F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen area_pixel_compute_source_index with
@@ -271,17 +274,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4 (&acc)
     for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[nt][j];
   const bool full = ch0 + 4 * NT <= p.Cout;
   if (p.bias) {
-    if (full) {
+    const float* pbias = p.bias + min(grp, p.wGmax) * p.Cout;
+    if (full && (p.wGmax == 0 || p.Cout % 4 == 0)) {
 #pragma unroll
       for (int q = 0; q < NT; ++q) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * q);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(pbias + ch0 + 4 * q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[4 * q + j] += bv[j];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 4 * NT; ++i)
-        if (ch0 + i < p.Cout) v[i] += p.bias[ch0 + i];
+        if (ch0 + i < p.Cout) v[i] += pbias[ch0 + i];
     }
   }
   if (p.addz) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
   const int n_base = blockIdx.y * BN;
   const int grp = blockIdx.z;
   {  // 8 independent 16-byte loads in flight per thread, then the LDS stores
-    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad;
     const int kv = p.Kpad >> 3, nvec = BN * kv;
     for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
       Vec8<T> w[8];
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(ConvP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int n_base = blockIdx.y * BN, grp = blockIdx.z;
   {
-    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad;
     const int kv = p.Kpad >> 3, nvec = BN * kv;
     for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
       Vec8<T> w[8];
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvP p) {
     const int iy = iy0 + t / p.k, ix = ix0 + t % p.k;
     tapmask |= (unsigned)(pv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) << t;
   }
-  const T* wl = (const T*)p.w + (long)(n_base + r) * p.Kpad + 8 * g;
+  const T* wl = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)(n_base + r) * p.Kpad + 8 * g;
 
   f32x4 acc[NT];
 #pragma unroll
@@ -1007,6 +1011,7 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   p.w = d->w; p.bias = d->bias; p.y = d->y; p.yCs = d->y_cstride; p.res = d->res; p.resCs = d->res_cstride;
   p.out_scale = d->out_scale; p.addz = d->addz; p.addzCs = d->addz_cstride; p.Hz = d->addz_H; p.Wz = d->addz_W;
   p.zsy = d->addz ? (float)d->addz_H / (float)d->Ho : 0.f; p.zsx = d->addz ? (float)d->addz_W / (float)d->Wo : 0.f; p.srcG = d->src_gstride; p.yG = d->y_gstride;
+  p.wG = d->w_gstride; p.wGmax = d->w_gmax > 0 ? d->w_gmax : 0;
   p.Kpad = conv_kpad(Cin, d->k);
   p.nchunks = 0;
   for (int s2 = 0; s2 < d->nsrc; ++s2) p.nchunks += (d->src_C[s2] + CONV_CH - 1) / CONV_CH;

@@ -84,7 +84,7 @@ def igemm_ok(srcs, k, s, p):
 
 
 def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=None, addz=None, out_scale=1.0,
-           ngroup=1, src_gstride=0, y_gstride=0, group_C=None):
+           ngroup=1, src_gstride=0, y_gstride=0, group_C=None, w_sets=1):
     """y = res + out_scale*act(conv(cat(srcs)) + bias + up2x(addz)).  srcs: list of 1-2 logical-NCHW tensors
     (source i is read through a nearest x2 upsample when up[i]).  With ngroup>1 `srcs[0]`/`out` are the group-0
     slices and *_gstride the element offsets between groups (channel count per group = group_C)."""
@@ -112,12 +112,19 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
     dtype, dev = x0.dtype, x0.device
 
     def build():
-        w, b = folded_fn()
-        if w.shape[1] != cin or w.shape[2] != k:
-            raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match Cin={cin} k={k}")
-        return pack_conv_weight(w, dtype, dev), (b.to(dev).contiguous() if b is not None else None), w.shape[0]
+        if w_sets == 1:
+            w, b = folded_fn()
+            ws, bs = [w], [b]
+        else:  # several weight sets (group g uses set min(g, w_sets-1)): packed back to back, biases stacked
+            ws, bs = zip(*folded_fn())
+        for w in ws:
+            if w.shape[1] != cin or w.shape[2] != k or w.shape[0] != ws[0].shape[0]:
+                raise ValueError(f"conv2d: weight {tuple(w.shape)} does not match Cin={cin} k={k}")
+        packs = [pack_conv_weight(w, dtype, dev) for w in ws]
+        bias = None if bs[0] is None else torch.cat([b.to(dev).float() for b in bs]).contiguous()
+        return torch.cat(packs), bias, ws[0].shape[0], packs[0].numel() // x0.element_size()
 
-    wp, bias, cout = mod._packed(_dev_key(x0, "igemm" + tag), build)
+    wp, bias, cout, wset_elems = mod._packed(_dev_key(x0, "igemm" + tag), build)
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     if out is None:
         out = L.empty_nhwc(B, cout * (ngroup if y_gstride == 0 and ngroup > 1 else 1), Ho, Wo, dtype, dev)
@@ -147,6 +154,7 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
             raise ValueError("conv2d: addz batch/channel/dtype mismatch")
         d.addz, d.addz_cstride, d.addz_H, d.addz_W = addz.data_ptr(), L.cstride(addz), addz.shape[2], addz.shape[3]
     d.ngroup, d.src_gstride, d.y_gstride = ngroup, src_gstride, y_gstride
+    d.w_gstride, d.w_gmax = (wset_elems, w_sets - 1) if w_sets > 1 else (0, 0)
     if TRACE is not None:
         M = B * Ho * Wo
         es = x0.element_size()

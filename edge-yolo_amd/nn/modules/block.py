@@ -66,7 +66,7 @@ class C2f(nn.Module):
         return self.cv2(buf, out=out)
 
 
-class C3(nn.Module):
+class C3(_Packed):
     """reference block.py:382-396."""
 
     def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
@@ -77,15 +77,21 @@ class C3(nn.Module):
         self.cv3 = Conv(2 * c_, c2, 1)
         self.m = nn.Sequential(*(Bottleneck(c_, c_, shortcut, g, k=((1, 1), (3, 3)), e=1.0) for _ in range(n)))
 
+    def _cv12(self):
+        """cv1 and cv2 are both 1x1 convs over the same input: stack their (BN-folded) filters -> one launch."""
+        (w1, b1), (w2, b2) = self.cv1.folded(), self.cv2.folded()
+        return torch.cat((w1, w2), 0), torch.cat((b1, b2), 0)
+
     def forward(self, x, out=None):
         x = L.as_nhwc(x)
         B, _, H, W = x.shape
         c_ = self.cv1.conv.out_channels
-        buf = L.empty_nhwc(B, 2 * c_, H, W, x.dtype, x.device)
-        t = self.cv1(x) if len(self.m) else self.cv1(x, out=buf[:, :c_])
-        for i, m in enumerate(self.m):
-            t = m(t, out=buf[:, :c_] if i == len(self.m) - 1 else None)
-        self.cv2(x, out=buf[:, c_:])
+        # buf = [cv1(x) -> m(.) in place | cv2(x)]: the bottleneck chain rewrites slot 0 in place (its last conv reads a
+        # temporary and adds slot 0 pixel-by-pixel as the residual), so cat() never happens
+        buf = ops.conv2d(self, [x], self._cv12, 1, 1, 0, L.ACT_SILU, tag="cv12")
+        t = buf[:, :c_]
+        for m in self.m:
+            t = m(t, out=buf[:, :c_])
         return self.cv3(buf, out=out)
 
 
@@ -316,6 +322,13 @@ class _WaveletEnhancer(_Packed):
         w = F.softplus(self.alpha.detach().float())
         return w / (w.sum() + 1e-6)  # block.py:3697-3698
 
+    def _subband_sets(self):
+        wl, bl = self.f_ll.folded()
+        wh, bh = self.f_h.folded()
+        w3 = torch.zeros_like(wh)
+        w3[:, :, 1:2, 1:2] = wl  # 1x1 == 3x3 with only the centre tap (pad 1)
+        return (w3, bl), (wh, bh)
+
     def _fuse_b(self):
         w, b = self.fuse.folded()
         return w[:, :self.c].contiguous(), b
@@ -339,9 +352,10 @@ class _WaveletEnhancer(_Packed):
         h = c // 2
         sub = ops.dwt_haar(b)  # (B,4c,H/2,W/2): LL|LH|HL|HH
         P = L.empty_nhwc(B, 2 * c, H // 2, W // 2, b.dtype, b.device)
-        self.f_ll(sub[:, :c], out=P[:, :h])
-        # the three high-frequency bands share f_h: one launch, 3 channel-offset groups
-        ops.conv2d(self.f_h, [sub[:, c:2 * c]], self.f_h.folded, 3, 1, 1, L.ACT_SILU, out=P[:, h:2 * h], ngroup=3, src_gstride=c, y_gstride=h)
+        # ONE launch for the four sub-band convs: group 0 = f_ll (a 1x1 conv written as a centre-tap 3x3) on LL, groups 1-3 =
+        # the shared f_h on LH, HL, HH (weight set min(g, 1)); the groups are channel-offset slices of `sub` and `P`
+        ops.conv2d(self, [sub[:, :c]], self._subband_sets, 3, 1, 1, L.ACT_SILU, out=P[:, :h], ngroup=4, src_gstride=c, y_gstride=h, w_sets=2,
+                   tag="sub")
         Z = ops.conv2d(self, [P], self._fuse_z, 1, 1, 0, L.ACT_NONE, tag="z")
         g = self._packed("tanh_gamma", lambda: float(torch.tanh(self.gamma.detach().float())))  # host scalar, cached (graph capture)
         return ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")

@@ -46,8 +46,9 @@ size_t ey_abi_sizeof(int which);
  *   y = res + out_scale * act( conv_k(cat_c(src0, src1)) + bias + bilinear_up2x(addz) )
  *
  * src[i] may be read through a nearest x2^up upsample (src_up = 0|1).  k in {1,3}, stride in {1,2}, pad = k/2.
- * `ngroup` > 1 runs the same weights over `ngroup` channel-offset slices (src0 += g*src_gstride,
- * y += g*y_gstride elements) — the three high-frequency sub-bands share f_h (block.py:3691-3694).
+ * `ngroup` > 1 runs over `ngroup` channel-offset slices (src0 += g*src_gstride, y += g*y_gstride elements) with
+ * weight set min(g, w_gmax) — the three high-frequency sub-bands share f_h, and f_ll (a 1x1 conv written as a
+ * centre-tap 3x3) rides in the same launch as group 0 (block.py:3688-3694).
  * Weights must be packed by ey_conv_pack_weight(). */
 typedef struct {
   int32_t dtype;
@@ -73,6 +74,9 @@ typedef struct {
   int32_t addz_H, addz_W;
   int32_t ngroup;
   int64_t src_gstride, y_gstride;
+  /* group g uses weight set min(g, w_gmax): w + that*w_gstride (elements of dtype), bias + that*Cout.  0/0 = shared. */
+  int64_t w_gstride;
+  int32_t w_gmax;
 } ey_conv_desc;
 
 /* Bytes of the packed weight buffer for a conv with Cout x (k*k*Cin) (Cin = sum of src_C). */
