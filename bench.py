@@ -89,8 +89,12 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_gather = os.environ.get("EY_FORCE_GATHER") == "1"  # exercise the RCCL gather path on a single GPU (world_size 1)
+    if world > 1 or force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     dtype = torch.float16 if a.dtype == "f16" else torch.float32
     conf, iou, max_det = 0.25, 0.7, 300
@@ -108,7 +112,7 @@ def main():
         boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
         return boxes, count
 
-    gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if world > 1 else None
+    gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if (world > 1 or force_gather) else None
     if a.no_pipeline:
         runner = GraphRunner(device_step)
         images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
@@ -189,7 +193,10 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if gather is not None and rank == 0:
+        rows = gather.results()
+        assert len(rows) == a.batch * world and all(r.shape[1] == 6 for r in rows)
+    if world > 1 or force_gather:
         dist.destroy_process_group()
 
 

@@ -758,6 +758,22 @@ static bool launch_conv(const ConvP& p, int ngroup, hipStream_t st) {
   return true;
 }
 
+// ---- tunables (defaults measured on MI355X; EY_* environment variables override them for sweeps)
+#include <stdlib.h>
+static long ey_env(const char* name, long dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atol(v) : dflt;
+}
+struct EyTune {
+  long tiles_per_wave = ey_env("EY_TPW", 0);          // ws: minimum tiles per wave before adding workgroups (0 = fill all slots)
+  long mt2_min_m = ey_env("EY_MT2_M", 300000);        // ws: 2 pixel blocks per wave from this many output pixels
+  long small_m = ey_env("EY_SMALL_M", 100000);        // small-M kernel below this many output pixels ...
+  long small_wbytes = ey_env("EY_SMALL_WMB", 48) << 20;  // ... while (#tiles x weight bytes) stays below this
+  long halo_min_c = ey_env("EY_HALO_MINC", 48);       // 3x3 halo kernel for Cin in [this, 64]
+  long ws_budget = ey_env("EY_WS_LDS_KB", 76) << 10;  // ws: preferred LDS per workgroup (2 workgroups per CU)
+  long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
+};
+static const EyTune& tune() { static EyTune t; return t; }
 // ---- weight-stationary dispatch
 static int ws_ls(int Kpad) { return ((Kpad >> 3) & 1) ? Kpad : Kpad + 8; }  // odd number of 16-byte (f16) units per row
 static const int WS_NT[5] = {8, 5, 4, 2, 1};
@@ -783,12 +799,17 @@ static bool ws_launch(ConvP p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   p.ntile = (M + 16 * MT - 1) / (16 * MT);
   const int ntiles_n = (conv_cout_pad(p.Cout)) / (16 * NT);
-  const int wg_per_cu = lds > 76 * 1024 ? 1 : 2;
+  const int wg_per_cu = lds > 76 * 1024 ? 1 : (int)tune().ws_wg_cu;
   // persistent grid: one workgroup per resident slot; tiles are dealt round-robin over workgroups first, then waves,
   // so a small layer still spreads over all CUs
   long cap = (long)256 * wg_per_cu / ((long)ntiles_n * ngroup);
   if (cap < 1) cap = 1;
   long gx = p.ntile < cap ? p.ntile : cap;
+  if (tune().tiles_per_wave > 0) {
+    long want = (p.ntile + 8 * tune().tiles_per_wave - 1) / (8 * tune().tiles_per_wave);
+    if (want < 1) want = 1;
+    if (want < gx) gx = want;
+  }
   dim3 grid((unsigned)gx, ntiles_n, ngroup);
   hipLaunchKernelGGL((conv_ws_kernel<T, NT, MT, KS>), grid, dim3(512), lds, st, p);
   return true;
@@ -798,7 +819,7 @@ template <typename T, int NT, int KS>
 static bool ws_launch_mt(const ConvP& p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   // enough wave tiles to give every SIMD work: 2 pixel blocks per wave when M is large, else 1
-  if (M >= 300000) return ws_launch<T, NT, 2, KS>(p, ngroup, st);  // measured: below this, more (smaller) wave tiles hide latency better
+  if (M >= tune().mt2_min_m) return ws_launch<T, NT, 2, KS>(p, ngroup, st);  // measured: below this, more (smaller) wave tiles hide latency better
   return ws_launch<T, NT, 1, KS>(p, ngroup, st);
 }
 
@@ -853,7 +874,7 @@ static int halo_pick_nt(const ConvP& p, int S) {
 
 template <typename T>
 static int dispatch_halo(ConvP p, int ngroup, hipStream_t st) {
-  if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || p.srcC[0] > 64 || p.srcC[0] < 48) return 0;  // measured: wins for Cin=64 on large maps
+  if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || p.srcC[0] > 64 || p.srcC[0] < tune().halo_min_c) return 0;  // measured: wins for Cin=64 on large maps
   const int S = p.stride;
   {  // the per-thread register halo holds HV=10 vectors
     const int MT = (S == 1) ? 2 : 1, HR = 7 * S + 3, HC = (16 * MT - 1) * S + 3;
@@ -903,8 +924,8 @@ static int small_pick_nt(int Cout, int es) {
 // from L2 stay a small total: (#16-pixel tiles) x (weight bytes) <= 48 MB.  Larger weights: weight-stationary kernel.
 #define EY_SMALL_M 100000
 static bool small_ok(int Cout, int Kpad, int k, long M, int es) {
-  if (k != 1 || M >= EY_SMALL_M) return false;
-  return ((M + 15) / 16) * (long)conv_cout_pad(Cout) * Kpad * es <= 48L * 1024 * 1024;
+  if (k != 1 || M >= tune().small_m) return false;
+  return ((M + 15) / 16) * (long)conv_cout_pad(Cout) * Kpad * es <= tune().small_wbytes;
 }
 
 template <typename T>
@@ -935,7 +956,7 @@ static int dispatch_small(ConvP p, int ngroup, hipStream_t st) {
 // returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
 template <typename T>
 static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
-  int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 76 * 1024);
+  int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), (size_t)tune().ws_budget);
   if (!nt) nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 156 * 1024);
   if (!nt) return 0;
   p.NTpack = conv_nt(p.Cout);
