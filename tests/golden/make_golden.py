@@ -187,10 +187,57 @@ def nms_cases():
     print("nms", meta)
 
 
+def metrics_cases():
+    """reference box_iou / match_predictions / ap_per_class on seeded synthetic detections and labels."""
+    from ultralytics.utils import metrics as rm
+    from ultralytics.engine.validator import BaseValidator
+    r = np.random.default_rng(7)
+    d = {}
+    tps, confs, pcls, tcls = [], [], [], []
+    iouv = torch.linspace(0.5, 0.95, 10)
+    holder = type("V", (), {"iouv": iouv})()
+    for img in range(12):
+        m = int(r.integers(0, 6))
+        lab = np.zeros((m, 5), np.float32)
+        lab[:, 0] = r.integers(0, 4, m)
+        xy = r.uniform(0, 500, (m, 2)); wh = r.uniform(20, 120, (m, 2))
+        lab[:, 1:3] = xy; lab[:, 3:5] = xy + wh
+        n = int(r.integers(0, 15))
+        det = np.zeros((n, 6), np.float32)
+        for k in range(n):
+            if m and r.random() < 0.6:  # jittered copy of a label
+                j = int(r.integers(0, m))
+                det[k, :4] = lab[j, 1:] + r.normal(0, 6, 4)
+                det[k, 5] = lab[j, 0] if r.random() < 0.85 else r.integers(0, 4)
+            else:
+                p0 = r.uniform(0, 500, 2); det[k, :2] = p0; det[k, 2:4] = p0 + r.uniform(20, 120, 2); det[k, 5] = r.integers(0, 4)
+            det[k, 4] = r.uniform(0.01, 1.0)
+        d[f"lab{img}"], d[f"det{img}"] = lab, det
+        if n:
+            if m:
+                iou = rm.box_iou(torch.tensor(lab[:, 1:]), torch.tensor(det[:, :4]))
+                d[f"iou{img}"] = iou.numpy()
+                c = BaseValidator.match_predictions(holder, torch.tensor(det[:, 5]), torch.tensor(lab[:, 0]), iou).numpy()
+            else:
+                c = np.zeros((n, 10), bool)
+            d[f"correct{img}"] = c
+            tps.append(c); confs.append(det[:, 4]); pcls.append(det[:, 5])
+        tcls.append(lab[:, 0])
+    out = rm.ap_per_class(np.concatenate(tps), np.concatenate(confs), np.concatenate(pcls), np.concatenate(tcls))
+    for k, v in zip(("tp", "fp", "p", "r", "f1", "ap", "classes"), out[:7]):
+        d["apc_" + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, "metrics_cases.npz"), **d)
+    print("metrics", out[5].mean())
+
+
 if __name__ == "__main__":
+    metrics_cases() if "--metrics-only" in sys.argv else None
+    if "--metrics-only" in sys.argv:
+        sys.exit(0)
     structure()
     ops_small()
     nms_cases()
+    metrics_cases()
     model_small("yolo11n-test.yaml", "edgeline_n_64")
     model_small("yolo11n.yaml", "yolo11n_64")
     for abl in ("GF2Detect", "lineattention", "DSC3K2_Wavelet", "tune"):
