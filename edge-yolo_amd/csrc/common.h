@@ -25,6 +25,10 @@ int ey_set_error(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
+// Row length (elements) of a packed conv weight row holding K = k*k*Cin values: +32 zero slack (masked tail lanes may read
+// past the row) and an ODD number of 16-byte f16 units, so the same stride is bank-conflict-free in LDS and a weight
+// tile is one contiguous block in global memory (staging = flat copy, no per-vector row arithmetic).
+static inline int ey_conv_kpad(int K) { const int kp = K + 32; return ((kp >> 3) & 1) ? kp : kp + 8; }
 static inline bool ey_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 static inline int ey_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
@@ -72,15 +76,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ey_rsrc(const void* base, unsi
 }
 template <typename T> struct BufLoad8;
 template <> struct BufLoad8<f16> {
-  static __device__ __forceinline__ void load(Vec8<f16>& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  // off: per-lane byte offset (VGPR), soff: wave-uniform byte offset (SGPR / immediate)
+  static __device__ __forceinline__ void load(Vec8<f16>& v, __amdgpu_buffer_rsrc_t r, unsigned off, int soff = 0) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, 0);
     v.v = __builtin_bit_cast(f16x8, t);
   }
 };
 template <> struct BufLoad8<float> {
-  static __device__ __forceinline__ void load(Vec8<float>& v, __amdgpu_buffer_rsrc_t r, unsigned off) {
-    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off + 16u), 0, 0);
+  static __device__ __forceinline__ void load(Vec8<float>& v, __amdgpu_buffer_rsrc_t r, unsigned off, int soff = 0) {
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff + 16, 0);
     v.lo = __builtin_bit_cast(f32x4, a);
     v.hi = __builtin_bit_cast(f32x4, b);
   }

@@ -370,21 +370,17 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
   const int r = lane & 15, g = lane >> 4;
   const int n_base = blockIdx.y * BN;
   const int grp = blockIdx.z;
-  {  // 8 independent 16-byte loads in flight per thread, then the LDS stores
+  {  // the weight tile is one contiguous block (LDS row stride == packed row stride): flat copy, 8 loads in flight per thread
     const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad;
-    const int kv = p.Kpad >> 3, nvec = BN * kv;
+    const int nvec = BN * (p.Kpad >> 3);
     for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
       Vec8<T> w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * 512;
-        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].load(wg + (long)row * p.Kpad + c8); }
-      }
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].load(wg + (long)(v0 + u * 512) * 8);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * 512;
-        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].store(wl + row * p.LSw + c8); }
-      }
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].store(wl + (v0 + u * 512) * 8);
     }
   }
   __syncthreads();
@@ -510,19 +506,15 @@ __global__ __launch_bounds__(512) void conv3_halo_kernel(ConvP p) {
   const int n_base = blockIdx.y * BN, grp = blockIdx.z;
   {
     const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad;
-    const int kv = p.Kpad >> 3, nvec = BN * kv;
+    const int nvec = BN * (p.Kpad >> 3);  // contiguous block, LDS row stride == packed row stride
     for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
       Vec8<T> w[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * 512;
-        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].load(wg + (long)row * p.Kpad + c8); }
-      }
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].load(wg + (long)(v0 + u * 512) * 8);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int v = v0 + u * 512;
-        if (v < nvec) { const int row = v / kv, c8 = (v - row * kv) << 3; w[u].store(wl + row * p.LSw + c8); }
-      }
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].store(wl + (v0 + u * 512) * 8);
     }
   }
   const __amdgpu_buffer_rsrc_t rs = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
@@ -688,6 +680,84 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvP p) {
   conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, grp);
 }
 
+// ================================================================================================================
+// Lean pointwise kernel (1x1, stride 1, <= 2 sources) for maps up to ~80x80.  Measured on MI355X (tools/micro): a lone
+// wave retires about one instruction per 2.5 ns and a kernel launch costs 1.6 us, so for layers that move a few MB the
+// run time is the per-wave instruction count plus the memory round trips, not bandwidth.  Hence: no LDS, no barrier,
+// no 64-bit or runtime-divisor arithmetic on the common path (GEO=false: pixel index == flat output index), pixel AND
+// weight fragments by buffer loads whose per-step address is a scalar offset (one instruction per fragment), every
+// fragment of up to BATCH k-steps in flight before the first MFMA, many small wave tiles (16 pixels x 16*NT channels)
+// so that every SIMD has a few waves to overlap.
+template <typename T, int NT, int BATCH, bool TWO, bool GEO>
+__global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int m_tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m_tile >= (int)p.ntile) return;  // whole wave
+  const int n_base = blockIdx.y * (16 * NT);
+  const int M = p.B * p.Ho * p.Wo;  // < 2^31 (host check)
+  const int m = m_tile * 16 + r;
+  const bool pv = m < M;
+  int b = 0, oy = 0, ox = 0;
+  unsigned voff0, voff1 = EY_OOB;
+  if constexpr (GEO) {  // an upsampled source or the bilinear addz needs (b, y, x)
+    const int hw = p.Ho * p.Wo, mm = pv ? m : 0;
+    b = mm / hw;
+    const int rem = mm - b * hw;
+    oy = rem / p.Wo;
+    ox = rem - oy * p.Wo;
+    const int u0 = p.srcUp[0];
+    voff0 = pv ? (unsigned)(((((b * (p.H >> u0)) + (oy >> u0)) * (p.W >> u0) + (ox >> u0)) * p.srcCs[0] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+    if constexpr (TWO) {
+      const int u1 = p.srcUp[1];
+      voff1 = pv ? (unsigned)(((((b * (p.H >> u1)) + (oy >> u1)) * (p.W >> u1) + (ox >> u1)) * p.srcCs[1] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+    }
+  } else {
+    voff0 = pv ? (unsigned)((m * p.srcCs[0] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+    if constexpr (TWO) voff1 = pv ? (unsigned)((m * p.srcCs[1] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+  }
+  const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(p.src[0], p.srcBytes[0]);
+  const __amdgpu_buffer_rsrc_t rs1 = TWO ? ey_rsrc(p.src[1], p.srcBytes[1]) : rs0;
+  // this wave's 16*NT packed weight rows: lane (r, g) reads row nt*16 + r, k offset 8g (+ scalar step offset)
+  const __amdgpu_buffer_rsrc_t rw = ey_rsrc((const T*)p.w + (long)n_base * p.Kpad, (unsigned)(16 * NT * p.Kpad * (int)sizeof(T)));
+  const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * (int)sizeof(T));
+  const int rowblk = 16 * p.Kpad * (int)sizeof(T);
+  const int C0 = p.srcC[0], S0 = (C0 + 31) >> 5;
+  const int C1 = TWO ? p.srcC[1] : 0;
+  const int nsteps = S0 + (TWO ? ((C1 + 31) >> 5) : 0);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+  for (int t0 = 0; t0 < nsteps; t0 += BATCH) {
+    Vec8<T> bf[BATCH], af[BATCH][NT];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int t = t0 + u;
+      if (t < nsteps) {  // wave-uniform
+        const bool second = TWO && t >= S0;
+        const int c = (second ? t - S0 : t) << 5;           // channel offset inside the source
+        const int kofs = second ? C0 + c : c;               // K offset inside the packed row
+        const bool cok = (c + 8 * g) < (second ? C1 : C0);  // channel tail: range check -> zeros
+        if (second) BufLoad8<T>::load(bf[u], rs1, cok ? voff1 : EY_OOB, c * (int)sizeof(T));
+        else BufLoad8<T>::load(bf[u], rs0, cok ? voff0 : EY_OOB, c * (int)sizeof(T));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[u][nt], rw, wvoff, nt * rowblk + kofs * (int)sizeof(T));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      if (t0 + u < nsteps) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mma16(af[u][nt], bf[u], acc[nt]);
+      }
+    }
+  }
+  if (!pv) return;
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int conv_nt(int Cout) {  // channels per block tile / 16
   if (Cout <= 16) return 1;
@@ -701,7 +771,7 @@ static int conv_nt(int Cout) {  // channels per block tile / 16
   return 8;
 }
 static int conv_cout_pad(int Cout) { int bn = 16 * conv_nt(Cout); return (Cout + bn - 1) / bn * bn; }
-static int conv_kpad(int Cin, int k) { return k * k * Cin + 32; }  // +32: masked tail lanes may read past a row
+static int conv_kpad(int Cin, int k) { return ey_conv_kpad(k * k * Cin); }
 
 extern "C" size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k) {
   return (size_t)conv_cout_pad(Cout) * conv_kpad(Cin, k) * (dtype == EY_F16 ? 2 : 4);
@@ -772,10 +842,13 @@ struct EyTune {
   long halo_min_c = ey_env("EY_HALO_MINC", 48);       // 3x3 halo kernel for Cin in [this, 64]
   long ws_budget = ey_env("EY_WS_LDS_KB", 76) << 10;  // ws: preferred LDS per workgroup (2 workgroups per CU)
   long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
+  long pw_m = ey_env("EY_PW_M", 110000);              // lean pointwise kernel below this many output pixels (0 = off)
+  long pw_waves = ey_env("EY_PW_WAVES", 3072);        // pw: prefer the widest channel tile that still leaves this many waves
+  long pw_wbytes = ey_env("EY_PW_WMB", 64) << 20;     // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this
 };
 static const EyTune& tune() { static EyTune t; return t; }
 // ---- weight-stationary dispatch
-static int ws_ls(int Kpad) { return ((Kpad >> 3) & 1) ? Kpad : Kpad + 8; }  // odd number of 16-byte (f16) units per row
+static int ws_ls(int Kpad) { return Kpad; }  // conv_kpad() already makes the row an odd number of 16-byte (f16) units
 static const int WS_NT[5] = {8, 5, 4, 2, 1};
 // largest NT (<= the packing NT, dividing it into whole 16-row blocks) whose weight tile fits `budget` bytes of LDS
 static int ws_pick_nt(int Cout, int Kpad, int es, size_t budget) {
@@ -799,7 +872,17 @@ static bool ws_launch(ConvP p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   p.ntile = (M + 16 * MT - 1) / (16 * MT);
   const int ntiles_n = (conv_cout_pad(p.Cout)) / (16 * NT);
-  const int wg_per_cu = lds > 76 * 1024 ? 1 : (int)tune().ws_wg_cu;
+  // resident workgroups per CU: LDS AND registers decide (a 512-thread workgroup of a 172-VGPR instantiation fits once per
+  // CU whatever its LDS footprint); a persistent grid larger than that runs in two rounds and stages every weight tile twice
+  static size_t occ_lds = ~(size_t)0;
+  static int occ = 1;
+  if (occ_lds != lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_ws_kernel<T, NT, MT, KS>, 512, lds) != hipSuccess || n < 1) n = 1;
+    occ = n;
+    occ_lds = lds;
+  }
+  const int wg_per_cu = occ < (int)tune().ws_wg_cu ? occ : (int)tune().ws_wg_cu;
   // persistent grid: one workgroup per resident slot; tiles are dealt round-robin over workgroups first, then waves,
   // so a small layer still spreads over all CUs
   long cap = (long)256 * wg_per_cu / ((long)ntiles_n * ngroup);
@@ -848,7 +931,15 @@ static int halo_launch(ConvP p, int ngroup, hipStream_t st) {
   }
   const long ntile = (long)p.B * ((p.Wo + TC - 1) / TC) * ((p.Ho + TR - 1) / TR);
   const int ntn = conv_cout_pad(p.Cout) / (16 * NT);
-  const int per_cu = lds > 78 * 1024 ? 1 : 2;
+  static size_t occ_lds = ~(size_t)0;
+  static int occ = 1;
+  if (occ_lds != lds) {  // resident workgroups per CU from LDS and registers (see ws_launch)
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv3_halo_kernel<T, NT, S>, 512, lds) != hipSuccess || n < 1) n = 1;
+    occ = n;
+    occ_lds = lds;
+  }
+  const int per_cu = occ < 2 ? occ : 2;
   long gx = (long)256 * per_cu / ((long)ntn * ngroup);
   if (gx < 1) gx = 1;
   if (gx > ntile) gx = ntile;
@@ -953,6 +1044,66 @@ static int dispatch_small(ConvP p, int ngroup, hipStream_t st) {
   }
 }
 
+// ---- lean pointwise dispatch
+static thread_local int g_last_variant = 0;  // kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels)
+
+static int pw_pick_nt(int Cout, long mtiles, int es) {
+  const int ntp = conv_nt(Cout), rows = conv_cout_pad(Cout) / 16;
+  const int opts[5] = {8, 5, 4, 2, 1};
+  int pick = 0;
+  for (int i = 0; i < 5; ++i) {
+    const int nt = opts[i];
+    if (nt > ntp || ntp % nt || (es == 4 && nt > 4)) continue;
+    pick = nt;  // candidates come widest first; keep narrowing until there are enough waves (but stay >= 2 for 16-byte stores)
+    if (mtiles * (rows / nt) >= tune().pw_waves || nt <= 2) break;
+  }
+  return pick;
+}
+
+template <typename T, int NT>
+static int pw_launch(const ConvP& p, bool two, bool geo, hipStream_t st) {
+  // k-steps in flight per wave: as many as keep the wave at <= ~128 VGPRs (4 waves per SIMD)
+  constexpr int BATCH = (sizeof(T) == 2 ? (NT <= 2 ? 8 : NT <= 5 ? 4 : 2) : (NT <= 2 ? 4 : 2));
+  const dim3 grid((unsigned)((p.ntile + 3) / 4), (unsigned)(conv_cout_pad(p.Cout) / (16 * NT)), 1);
+  if (two) {
+    if (geo) hipLaunchKernelGGL((conv_pw_kernel<T, NT, BATCH, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_pw_kernel<T, NT, BATCH, true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (geo) hipLaunchKernelGGL((conv_pw_kernel<T, NT, BATCH, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_pw_kernel<T, NT, BATCH, false, false>), grid, dim3(256), 0, st, p);
+  }
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(pw): %s", hipGetErrorString(e_));
+  g_last_variant = 4000 + NT * 10 + (two ? 2 : 1);
+  return 1;
+}
+
+template <typename T>
+static int dispatch_pw(ConvP p, int ngroup, hipStream_t st) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  if (p.k != 1 || p.stride != 1 || ngroup != 1 || M >= tune().pw_m) return 0;
+  if (((M + 15) / 16) * (long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) > tune().pw_wbytes) return 0;  // every wave re-reads its weight rows
+  if ((long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) >= (1L << 31)) return 0;
+  for (int s2 = 0; s2 < p.nsrc; ++s2) {
+    const int up = p.srcUp[s2];
+    const long npix = (long)p.B * (p.H >> up) * (p.W >> up);
+    const long bytes = ((npix - 1) * p.srcCs[s2] + p.srcC[s2]) * (long)sizeof(T);
+    if (bytes >= (1L << 31)) return 0;
+    p.srcBytes[s2] = (unsigned)bytes;
+  }
+  p.ntile = (M + 15) / 16;
+  p.NTpack = conv_nt(p.Cout);
+  const bool two = p.nsrc == 2, geo = p.addz != nullptr || p.srcUp[0] || (two && p.srcUp[1]);
+  switch (pw_pick_nt(p.Cout, p.ntile, sizeof(T))) {
+    case 8: if constexpr (sizeof(T) == 2) return pw_launch<T, 8>(p, two, geo, st); else return 0;
+    case 5: if constexpr (sizeof(T) == 2) return pw_launch<T, 5>(p, two, geo, st); else return 0;
+    case 4: return pw_launch<T, 4>(p, two, geo, st);
+    case 2: return pw_launch<T, 2>(p, two, geo, st);
+    case 1: return pw_launch<T, 1>(p, two, geo, st);
+  }
+  return 0;
+}
+
 // returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
 template <typename T>
 static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
@@ -1045,6 +1196,9 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
       (!d->res || ((d->res_cstride * es) % 16 == 0 && ey_aligned(d->res, 16))))
     p.vec_store = 2;  // 16-byte epilogue accesses allowed
   hipStream_t st = (hipStream_t)stream;
+  g_last_variant = 0;
+  const int pw = d->dtype == EY_F16 ? dispatch_pw<f16>(p, ngroup, st) : dispatch_pw<float>(p, ngroup, st);
+  if (pw != 0) return pw < 0 ? pw : EY_OK;
   const int sm = d->dtype == EY_F16 ? dispatch_small<f16>(p, ngroup, st) : dispatch_small<float>(p, ngroup, st);
   if (sm != 0) return sm < 0 ? sm : EY_OK;
   const int halo = d->dtype == EY_F16 ? dispatch_halo<f16>(p, ngroup, st) : dispatch_halo<float>(p, ngroup, st);
@@ -1077,3 +1231,6 @@ extern "C" int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, 
   return nt * 10 + ((M + 127) / 128 * ntiles * (ngroup > 0 ? ngroup : 1) >= 512 ? 2 : 1);
 }
 extern "C" int ey_conv_pack_nt(int Cout) { return conv_nt(Cout); }
+// kind*1000 + NT*10 + x of the kernel the last ey_conv2d on this thread launched; 0 when ey_conv_variant() describes it
+// (kind 4 = conv_pw_kernel<T,NT,..>, x = number of sources).
+extern "C" int ey_conv_last_variant(void) { return g_last_variant; }

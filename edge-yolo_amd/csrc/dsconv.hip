@@ -230,8 +230,15 @@ static int ds_launch(DsP p, hipStream_t st) {
     reserved = lds;
   }
   const int ntn = (p.Cout + 16 * NT - 1) / (16 * NT);
-  int per_cu = (int)((size_t)150 * 1024 / lds);  // resident workgroups per CU the LDS allows (the grid is persistent)
-  per_cu = per_cu < 1 ? 1 : (per_cu > 6 ? 6 : per_cu);
+  static size_t occ_lds = ~(size_t)0;
+  static int occ = 1;
+  if (occ_lds != lds) {  // resident workgroups per CU the LDS and the registers allow (the grid is persistent)
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dsconv_kernel<T, K, NT>, 256, lds) != hipSuccess || n < 1) n = 1;
+    occ = n;
+    occ_lds = lds;
+  }
+  int per_cu = occ > 6 ? 6 : occ;
   long gx = (long)256 * per_cu / ntn;
   if (gx < 1) gx = 1;
   if (gx > p.ntile) gx = p.ntile;
@@ -276,7 +283,7 @@ extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int 
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
   p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)xbytes;
   p.wdw = w_dw_kkc; p.dwbias = dw_bias; p.dwact = dw_act; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
-  p.Kpad = Cin + 32;
+  p.Kpad = ey_conv_kpad(Cin);
   p.NTpack = ds_conv_nt(Cout);
   p.tilesX = (W + DS_TW - 1) / DS_TW; p.tilesY = (H + DS_TH - 1) / DS_TH;
   p.ntile = (long)B * p.tilesX * p.tilesY;

@@ -164,9 +164,13 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
                 f"conv3_halo_kernel<{tn},{var % 1000 // 10},{s}>" if var >= 2000 else
                 f"conv_ws_kernel<{tn},{var % 1000 // 10},{var % 10},{k}>" if var >= 1000 else f"conv_igemm_kernel<{tn},{var // 10},{var % 10}>")
         nbytes = ngroup * (_nb(*srcs) + M * cout * es * (2 if res is not None else 1) + _nb(addz)) + cout * cin * k * k * es
-        with _tr(name, nbytes, 2.0 * ngroup * M * cout * cin * k * k,
-                 note=f"{cin}->{cout} k{k}s{s} {H}x{W} g{ngroup}{' +res' if res is not None else ''}{' +addz' if addz is not None else ''}{' 2src' if len(srcs) > 1 else ''}"):
+        rec = _tr(name, nbytes, 2.0 * ngroup * M * cout * cin * k * k,
+                  note=f"{cin}->{cout} k{k}s{s} {H}x{W} g{ngroup}{' +res' if res is not None else ''}{' +addz' if addz is not None else ''}{' 2src' if len(srcs) > 1 else ''}")
+        with rec:
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
+            lv = L.lib().ey_conv_last_variant()
+            if lv >= 4000:
+                rec.kernel = f"conv_pw_kernel<{tn},{lv % 1000 // 10}>"
         return out
     L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
     return out
