@@ -773,6 +773,7 @@ static int conv_nt(int Cout) {  // channels per block tile / 16
 static int conv_cout_pad(int Cout) { int bn = 16 * conv_nt(Cout); return (Cout + bn - 1) / bn * bn; }
 static int conv_kpad(int Cin, int k) { return ey_conv_kpad(k * k * Cin); }
 
+#if EY_CONV_PART == 16
 extern "C" size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k) {
   return (size_t)conv_cout_pad(Cout) * conv_kpad(Cin, k) * (dtype == EY_F16 ? 2 : 4);
 }
@@ -799,6 +800,8 @@ extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const fl
   }
   return EY_OK;
 }
+
+#endif
 
 template <typename T, int NT, int MT>
 static bool conv_lds_ok() {  // one-time opt-in to > 64 KiB of dynamic LDS for the big-tile / f32 variants
@@ -1045,7 +1048,12 @@ static int dispatch_small(ConvP p, int ngroup, hipStream_t st) {
 }
 
 // ---- lean pointwise dispatch
-static thread_local int g_last_variant = 0;  // kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels)
+// kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels); defined in the f16 translation unit
+#if EY_CONV_PART == 16
+thread_local int g_last_variant = 0;
+#else
+extern thread_local int g_last_variant;
+#endif
 
 static int pw_pick_nt(int Cout, long mtiles, int es) {
   const int ntp = conv_nt(Cout), rows = conv_cout_pad(Cout) / 16;
@@ -1145,6 +1153,28 @@ static int dispatch_conv(const ConvP& p, int ngroup, hipStream_t st) {
   return EY_OK;
 }
 
+// dispatch order: lean pointwise -> small-M -> 3x3 halo tile -> weight-stationary -> K-chunked fallback
+template <typename T>
+static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
+  const int pw = dispatch_pw<T>(p, ngroup, st);
+  if (pw != 0) return pw < 0 ? pw : EY_OK;
+  const int sm = dispatch_small<T>(p, ngroup, st);
+  if (sm != 0) return sm < 0 ? sm : EY_OK;
+  const int halo = dispatch_halo<T>(p, ngroup, st);
+  if (halo != 0) return halo < 0 ? halo : EY_OK;
+  const int ws = dispatch_ws<T>(p, ngroup, st);
+  if (ws != 0) return ws < 0 ? ws : EY_OK;
+  return dispatch_conv<T>(p, ngroup, st);
+}
+
+// the f16 and f32 instantiations live in two translation units (conv_f16.hip / conv_f32.hip) so that they compile in parallel
+int ey_conv2d_run_f16(const ConvP& p, int ngroup, hipStream_t st);
+int ey_conv2d_run_f32(const ConvP& p, int ngroup, hipStream_t st);
+#if EY_CONV_PART == 32
+int ey_conv2d_run_f32(const ConvP& p, int ngroup, hipStream_t st) { return conv2d_typed<float>(p, ngroup, st); }
+#else
+int ey_conv2d_run_f16(const ConvP& p, int ngroup, hipStream_t st) { return conv2d_typed<f16>(p, ngroup, st); }
+
 extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   EY_CHECK(d, "conv: null desc");
   EY_CHECK(d->dtype == EY_F16 || d->dtype == EY_F32, "conv: bad dtype %d", d->dtype);
@@ -1197,15 +1227,7 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
     p.vec_store = 2;  // 16-byte epilogue accesses allowed
   hipStream_t st = (hipStream_t)stream;
   g_last_variant = 0;
-  const int pw = d->dtype == EY_F16 ? dispatch_pw<f16>(p, ngroup, st) : dispatch_pw<float>(p, ngroup, st);
-  if (pw != 0) return pw < 0 ? pw : EY_OK;
-  const int sm = d->dtype == EY_F16 ? dispatch_small<f16>(p, ngroup, st) : dispatch_small<float>(p, ngroup, st);
-  if (sm != 0) return sm < 0 ? sm : EY_OK;
-  const int halo = d->dtype == EY_F16 ? dispatch_halo<f16>(p, ngroup, st) : dispatch_halo<float>(p, ngroup, st);
-  if (halo != 0) return halo < 0 ? halo : EY_OK;
-  const int ws = d->dtype == EY_F16 ? dispatch_ws<f16>(p, ngroup, st) : dispatch_ws<float>(p, ngroup, st);
-  if (ws != 0) return ws < 0 ? ws : EY_OK;
-  return d->dtype == EY_F16 ? dispatch_conv<f16>(p, ngroup, st) : dispatch_conv<float>(p, ngroup, st);
+  return d->dtype == EY_F16 ? ey_conv2d_run_f16(p, ngroup, st) : ey_conv2d_run_f32(p, ngroup, st);
 }
 
 // Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only): kind*1000 + NT*10 + MT,
@@ -1234,3 +1256,4 @@ extern "C" int ey_conv_pack_nt(int Cout) { return conv_nt(Cout); }
 // kind*1000 + NT*10 + x of the kernel the last ey_conv2d on this thread launched; 0 when ey_conv_variant() describes it
 // (kind 4 = conv_pw_kernel<T,NT,..>, x = number of sources).
 extern "C" int ey_conv_last_variant(void) { return g_last_variant; }
+#endif  // EY_CONV_PART

@@ -442,3 +442,90 @@ extern "C" int ey_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void
   EY_LAUNCH_CHECK("ey_nhwc_to_nchw");
   return EY_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// GPU pre-processing: LetterBox (data/augment.py:1556-1591: cv2.resize INTER_LINEAR + copyMakeBorder 114)
+// + BasePredictor.preprocess (engine/predictor.py:123-133: BGR->RGB, HWC->CHW, uint8 -> f16/f32, /255) as ONE kernel from
+// the raw uint8 image.  The resize restates OpenCV's 8-bit INTER_LINEAR fixed-point path (resize.cpp: 11-bit
+// coefficients `saturate_cast<short>(w*2048)`, horizontal pass in int32, vertical pass
+// `(((b0*(r0>>4))>>16) + ((b1*(r1>>4))>>16) + 2) >> 2`) so the uint8 stage is integer-exact and identical to the CPU
+// oracle; cv2 itself is not in the build image, so equality with cv2 is "parity unpinned" (see oracle/letterbox.py).
+struct LbCoef { int s0, s1, a0, a1; };
+__device__ __forceinline__ LbCoef lb_coef(int d, double scale, int ssize) {
+  // fx = (float)((dx+0.5)*scale - 0.5); sx = floor(fx); fx -= sx  (no fma: the oracle evaluates the same IEEE operations)
+  float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+  int s = (int)floorf(f);
+  f = __fsub_rn(f, (float)s);
+  if (s < 0) { f = 0.f; s = 0; }
+  if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+  LbCoef c;
+  c.s0 = s;
+  c.s1 = min(s + 1, ssize - 1);
+  c.a0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+  c.a1 = __float2int_rn(__fmul_rn(f, 2048.f));
+  return c;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int sh, int sw, int srow, T* __restrict__ dst, int H, int W,
+                                                        int nh, int nw, int top, int left, int pad, int swap_rb, double scale_x, double scale_y) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  int v[3] = {pad, pad, pad};
+  const int dx = x - left, dy = y - top;
+  if (dx >= 0 && dx < nw && dy >= 0 && dy < nh) {
+    if (nh == sh && nw == sw) {  // LetterBox skips cv2.resize when the size is unchanged
+      const uint8_t* p = src + (long)dy * srow + dx * 3;
+      v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+    } else if (sw == 2 * nw && sh == 2 * nh) {  // cv::resize turns an exact 2x INTER_LINEAR decimation into the 2x2 box average
+      const uint8_t* r0 = src + (long)(2 * dy) * srow + 6 * dx;
+      const uint8_t* r1 = r0 + srow;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = (r0[c] + r0[3 + c] + r1[c] + r1[3 + c] + 2) >> 2;
+    } else {
+      const LbCoef cx = lb_coef(dx, scale_x, sw);
+      // the vertical pass keeps its fractional weights at the borders and clamps the two rows (resizeGeneric_Invoker)
+      float fy = (float)__dsub_rn(__dmul_rn((double)dy + 0.5, scale_y), 0.5);
+      const int sy = (int)floorf(fy);
+      fy = __fsub_rn(fy, (float)sy);
+      const int b0 = __float2int_rn(__fmul_rn(__fsub_rn(1.f, fy), 2048.f)), b1 = __float2int_rn(__fmul_rn(fy, 2048.f));
+      const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+      const uint8_t* r0 = src + (long)y0 * srow;
+      const uint8_t* r1 = src + (long)y1 * srow;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0 = r0[cx.s0 * 3 + c] * cx.a0 + r0[cx.s1 * 3 + c] * cx.a1;
+        const int h1 = r1[cx.s0 * 3 + c] * cx.a0 + r1[cx.s1 * 3 + c] * cx.a1;
+        const int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v[c] = min(max(o, 0), 255);
+      }
+    }
+  }
+  const long plane = (long)H * W, o = (long)y * W + x;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = swap_rb ? 2 - c : c;  // output plane c takes source channel sc (BGR -> RGB)
+    dst[c * plane + o] = from_f<T>(__fdiv_rn((float)v[sc], 255.f));
+  }
+}
+
+extern "C" int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, int src_w, int src_row_bytes, void* dst_chw, int H, int W, int new_h,
+                            int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream) {
+  EY_CHECK(src_hwc && dst_chw, "letterbox: null pointer");
+  EY_CHECK(out_dtype == EY_F16 || out_dtype == EY_F32, "letterbox: bad dtype");
+  EY_CHECK(src_h > 0 && src_w > 0 && src_row_bytes >= 3 * src_w && H > 0 && W > 0, "letterbox: bad extent");
+  EY_CHECK(new_h > 0 && new_w > 0 && top >= 0 && left >= 0 && top + new_h <= H && left + new_w <= W, "letterbox: resized image (%dx%d at %d,%d) outside the %dx%d canvas",
+           new_h, new_w, top, left, H, W);
+  EY_CHECK(pad_value >= 0 && pad_value <= 255, "letterbox: pad value");
+  // cv::resize: inv_scale = dsize/ssize (double); scale = 1/inv_scale
+  const double scale_x = 1.0 / ((double)new_w / (double)src_w), scale_y = 1.0 / ((double)new_h / (double)src_h);
+  dim3 grid((W + 255) / 256, H);
+  if (out_dtype == EY_F16)
+    hipLaunchKernelGGL(letterbox_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, (f16*)dst_chw, H, W, new_h, new_w, top, left,
+                       pad_value, swap_rb, scale_x, scale_y);
+  else
+    hipLaunchKernelGGL(letterbox_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, (float*)dst_chw, H, W, new_h, new_w, top, left,
+                       pad_value, swap_rb, scale_x, scale_y);
+  EY_LAUNCH_CHECK("ey_letterbox");
+  return EY_OK;
+}

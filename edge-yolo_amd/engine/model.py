@@ -99,6 +99,7 @@ class Model(torch.nn.Module):
             self.predictor = DetectionPredictor(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
                                                 agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=args["graph"])
             self._pred_key = key
+        self.predictor.imgsz = kwargs.get("imgsz", 640)  # letterbox target for ndarray sources (reference cfg default 640)
         results = self.predictor(source)
         return iter(results) if stream else results
 

@@ -155,7 +155,7 @@ class DetectionPredictor:
         """Tensor sources: BCHW float in [0,1] (reference LoadTensor, data/loaders.py:516-586).  ndarray / list sources:
         HWC uint8 BGR images, letterboxed to a common stride-32 shape on the host (reference predictor.py:116-161)."""
         if not isinstance(im, torch.Tensor):
-            im = self._letterbox_batch(im)
+            return self._letterbox_batch(im, getattr(self, "imgsz", 640))
         if im.dim() == 3:
             im = im[None]
         if im.dim() != 4 or im.shape[2] % 32 or im.shape[3] % 32:
@@ -165,22 +165,15 @@ class DetectionPredictor:
         im = im.to(self.device)
         return (im.half() if self.half else im.float()).contiguous()
 
-    def _letterbox_batch(self, ims, new_shape=640, stride=32, pad=114):
+    def _letterbox_batch(self, ims, new_shape=640):
+        """reference pre_transform + preprocess (predictor.py:123-161) on the GPU: LetterBox geometry on the host, one
+        `ey_letterbox` launch per image (resize + pad 114 + BGR->RGB + CHW + /255) into the batch tensor."""
+        from ..data.augment import LetterBox
         ims = ims if isinstance(ims, (list, tuple)) else [ims]
         self._orig = [np.asarray(a) for a in ims]
-        out = []
-        for a in self._orig:
-            h, w = a.shape[:2]
-            r = min(new_shape / h, new_shape / w)
-            nh, nw = int(round(h * r)), int(round(w * r))
-            t = torch.from_numpy(np.ascontiguousarray(a[..., ::-1])).permute(2, 0, 1)[None].float()  # BGR->RGB
-            if (nh, nw) != (h, w):
-                t = torch.nn.functional.interpolate(t, size=(nh, nw), mode="bilinear", align_corners=False)
-            canvas = torch.full((1, 3, new_shape, new_shape), float(pad))
-            top, left = int(round((new_shape - nh) / 2 - 0.1)), int(round((new_shape - nw) / 2 - 0.1))
-            canvas[:, :, top:top + nh, left:left + nw] = t
-            out.append(canvas / 255.0)
-        return torch.cat(out)
+        same_shapes = len({a.shape for a in self._orig}) == 1
+        lb = LetterBox(new_shape, auto=same_shapes, stride=int(max(self.model.stride)) if hasattr(self.model, "stride") else 32)
+        return lb.batch(self._orig, self.device, torch.float16 if self.half else torch.float32)
 
     def __call__(self, source):
         with self._lock:

@@ -144,6 +144,14 @@ int ey_copy_nhwc(int dtype, int B, int H, int W, int C, int up, const void* src,
 int ey_nchw_to_nhwc(int dtype, int B, int C, int H, int W, const void* src, void* dst, int dst_cstride, ey_stream_t stream);
 int ey_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* src, int src_cstride, void* dst, ey_stream_t stream);
 
+/* ---- GPU pre-processing: LetterBox.__call__ (data/augment.py:1556-1591: cv2.resize INTER_LINEAR to
+ * (new_h,new_w) + copyMakeBorder with 114) and BasePredictor.preprocess (engine/predictor.py:123-133: BGR->RGB,
+ * HWC->CHW, uint8 -> f16/f32, /255) for ONE image, as one kernel.  src: device uint8 [src_h][src_w][3] (row pitch
+ * src_row_bytes); dst: one [3][H][W] image slot of the NCHW batch tensor (out_dtype).  The caller computes the
+ * LetterBox geometry (new size, top/left padding); the resize follows OpenCV's 8-bit fixed-point INTER_LINEAR path. */
+int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, int src_w, int src_row_bytes, void* dst_chw, int H, int W,
+                 int new_h, int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream);
+
 /* ---- K8a: linear attention core (LinearAttention.forward, block.py:3360-3373) between the qkv and proj convs.
  * qkv [B,N,3C] channel order [q(h0..)|k|v] (block.py:3364); y [B,N,C]:  k=softmax_d(k); q=softmax_N(q);
  * ctx_h = k_h^T v_h; y_h = q_h ctx_h.  head_dim = C/heads <= 64. */
