@@ -758,6 +758,155 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p) {
   conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, 0);
 }
 
+// ================================================================================================================
+// Register-stationary pointwise kernel for LARGE maps with few channels (1x1, stride 1, Cin <= 128, <= 2 sources): the whole
+// [16*NT][K] weight tile of a wave is KS*NT MFMA fragments -- it lives in registers for the life of a persistent wave, as
+// does the bias.  A wave then walks 16-pixel tiles: KS buffer loads (next tile's already in flight), KS*NT MFMAs, a short
+// epilogue, one or two wide stores -- a few dozen instructions per tile, no LDS, no barrier.  These layers (160x160 and 80x80
+// maps, 16-96 channels) move 50-100 MB and are bound by how fast waves can issue loads/stores, not by arithmetic.
+template <typename T, int NT, int KS, bool TWO, bool GEO>
+__global__ __launch_bounds__(256) void conv_pwr_kernel(ConvP p) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * (16 * NT);
+  const int M = p.B * p.Ho * p.Wo;  // < 2^31 (host check)
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+  const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(p.src[0], p.srcBytes[0]);
+  const __amdgpu_buffer_rsrc_t rs1 = TWO ? ey_rsrc(p.src[1], p.srcBytes[1]) : rs0;
+  const int C0 = p.srcC[0], S0 = (C0 + 31) >> 5, C1 = TWO ? p.srcC[1] : 0;
+  // ---- weights and bias -> registers (once)
+  Vec8<T> af[KS][NT];
+  {
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc((const T*)p.w + (long)n_base * p.Kpad, (unsigned)(16 * NT * p.Kpad * (int)sizeof(T)));
+    const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * (int)sizeof(T));
+    const int rowblk = 16 * p.Kpad * (int)sizeof(T);
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      const bool second = TWO && t >= S0;
+      const int kofs = second ? C0 + ((t - S0) << 5) : (t << 5);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[t][nt], rw, wvoff, nt * rowblk + kofs * (int)sizeof(T));
+    }
+  }
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  float bias[4 * NT];
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) bias[i] = (p.bias && ch0 + i < p.Cout) ? p.bias[ch0 + i] : 0.f;
+  // per-step channel-tail predicate and scalar byte offset inside the source
+  bool cok[KS];
+  int coff[KS];
+#pragma unroll
+  for (int t = 0; t < KS; ++t) {
+    const bool second = TWO && t >= S0;
+    const int c = (second ? t - S0 : t) << 5;
+    cok[t] = (c + 8 * g) < (second ? C1 : C0);
+    coff[t] = c * (int)sizeof(T);
+  }
+  const int hw = p.Ho * p.Wo;
+  const int u0 = p.srcUp[0], u1 = TWO ? p.srcUp[1] : 0;
+
+  auto issue = [&](int tile, Vec8<T> (&bf)[KS], int& b, int& oy, int& ox) {
+    const int m = tile * 16 + r;
+    const bool pv = m < M;
+    unsigned v0, v1 = EY_OOB;
+    if constexpr (GEO) {
+      const int mm = pv ? m : 0;
+      b = mm / hw;
+      const int rem = mm - b * hw;
+      oy = rem / p.Wo;
+      ox = rem - oy * p.Wo;
+      v0 = pv ? (unsigned)(((((b * (p.H >> u0)) + (oy >> u0)) * (p.W >> u0) + (ox >> u0)) * p.srcCs[0] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+      if constexpr (TWO) v1 = pv ? (unsigned)(((((b * (p.H >> u1)) + (oy >> u1)) * (p.W >> u1) + (ox >> u1)) * p.srcCs[1] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+    } else {
+      v0 = pv ? (unsigned)((m * p.srcCs[0] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+      if constexpr (TWO) v1 = pv ? (unsigned)((m * p.srcCs[1] + 8 * g) * (int)sizeof(T)) : EY_OOB;
+    }
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+      if (TWO && t >= S0) BufLoad8<T>::load(bf[t], rs1, cok[t] ? v1 : EY_OOB, coff[t]);
+      else BufLoad8<T>::load(bf[t], rs0, cok[t] ? v0 : EY_OOB, coff[t]);
+    }
+  };
+
+  Vec8<T> cur[KS], nxt[KS];
+  int b = 0, oy = 0, ox = 0, nb = 0, noy = 0, nox = 0;
+  int tile = wave_id;
+  if (tile < (int)p.ntile) issue(tile, cur, b, oy, ox);
+  for (; tile < (int)p.ntile; tile += nwave) {
+    const int ntile = tile + nwave;
+    if (ntile < (int)p.ntile) issue(ntile, nxt, nb, noy, nox);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = mma16(af[t][nt], cur[t], acc[nt]);
+    const int m = tile * 16 + r;
+    if (m < M) {
+      float v[4 * NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[nt][j] + bias[4 * nt + j];
+      if constexpr (GEO) {
+        if (p.addz) {  // bilinear (align_corners=False) resize of the half-resolution pre-activation term, see conv_epilogue
+          const int Hz = p.Hz, Wz = p.Wz;
+          const float sy = fmaxf(p.zsy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(p.zsx * (ox + 0.5f) - 0.5f, 0.f);
+          const int y0 = (int)sy, x0 = (int)sx;
+          const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
+          const float ly1 = sy - y0, lx1 = sx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+          const T* z = (const T*)p.addz + ch0;
+          const T* z00 = z + ((long)(b * Hz + y0) * Wz + x0) * p.addzCs;
+          const T* z01 = z + ((long)(b * Hz + y0) * Wz + x1) * p.addzCs;
+          const T* z10 = z + ((long)(b * Hz + y1) * Wz + x0) * p.addzCs;
+          const T* z11 = z + ((long)(b * Hz + y1) * Wz + x1) * p.addzCs;
+#pragma unroll
+          for (int q = 0; q < NT; ++q) {
+            float a00[4], a01[4], a10[4], a11[4];
+            load4(z00 + 4 * q, a00); load4(z01 + 4 * q, a01); load4(z10 + 4 * q, a10); load4(z11 + 4 * q, a11);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+      T* yp = (T*)p.y + (long)m * p.yCs + ch0;
+      const T* rp = p.res ? (const T*)p.res + (long)m * p.resCs + ch0 : nullptr;
+      if (sizeof(T) == 2 && NT % 2 == 0 && p.vec_store > 1) {
+#pragma unroll
+        for (int q = 0; q < NT / 2; ++q) {
+          if (rp) {
+            Vec8<T> rr;
+            rr.load(rp + 8 * q);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[8 * q + j] += rr.get(j);
+          }
+          Vec8<T> o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o.set(j, v[8 * q + j]);
+          o.store(yp + 8 * q);
+        }
+      } else {  // 4-element accesses (the host only dispatches here when the views allow them and Cout % (4*NT...) holds)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          if (rp) {
+            float rr[4];
+            load4(rp + 4 * q, rr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * q + j] += rr[j];
+          }
+          store4(yp + 4 * q, v + 4 * q);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KS; ++t) cur[t] = nxt[t];
+    b = nb; oy = noy; ox = nox;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int conv_nt(int Cout) {  // channels per block tile / 16
   if (Cout <= 16) return 1;
@@ -845,6 +994,9 @@ struct EyTune {
   long halo_min_c = ey_env("EY_HALO_MINC", 48);       // 3x3 halo kernel for Cin in [this, 64]
   long ws_budget = ey_env("EY_WS_LDS_KB", 76) << 10;  // ws: preferred LDS per workgroup (2 workgroups per CU)
   long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
+  long ws_k3_minnt = ey_env("EY_WS_K3_MINNT", 0);     // 3x3: use the K-chunked kernel when the weight-stationary tile would cover fewer than this many 16-channel blocks (and not all of Cout)
+  long pwr_m = ey_env("EY_PWR_M", 110000);            // register-stationary pointwise kernel from this many output pixels (huge value = off)
+  long pwr_frags = ey_env("EY_PWR_FRAGS", 16);        // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
   long pw_m = ey_env("EY_PW_M", 110000);              // lean pointwise kernel below this many output pixels (0 = off)
   long pw_waves = ey_env("EY_PW_WAVES", 3072);        // pw: prefer the widest channel tile that still leaves this many waves
   long pw_wbytes = ey_env("EY_PW_WMB", 64) << 20;     // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this
@@ -1086,6 +1238,76 @@ static int pw_launch(const ConvP& p, bool two, bool geo, hipStream_t st) {
   return 1;
 }
 
+// ---- register-stationary pointwise dispatch (large maps, few channels)
+template <typename T, int NT, int KS, bool TWO, bool GEO>
+static int pwr_launch2(const ConvP& p, hipStream_t st) {
+  // persistent grid = exactly the waves that are resident at once (register-limited), tiles dealt round-robin
+  static int occ = 0;
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_pwr_kernel<T, NT, KS, TWO, GEO>, 256, 0) != hipSuccess || n < 1) n = 1;
+    occ = n > 4 ? 4 : n;
+  }
+  const unsigned ny = (unsigned)(conv_cout_pad(p.Cout) / (16 * NT));
+  long gx = (long)256 * occ / ny;
+  const long need = (p.ntile + 3) / 4;
+  if (gx > need) gx = need;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((conv_pwr_kernel<T, NT, KS, TWO, GEO>), dim3((unsigned)gx, ny, 1), dim3(256), 0, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(pwr): %s", hipGetErrorString(e_));
+  g_last_variant = 5000 + NT * 10 + KS;
+  return 1;
+}
+
+template <typename T, int NT, int KS>
+static int pwr_launch(const ConvP& p, bool two, bool geo, hipStream_t st) {
+  if (two) return geo ? pwr_launch2<T, NT, KS, true, true>(p, st) : pwr_launch2<T, NT, KS, true, false>(p, st);
+  return geo ? pwr_launch2<T, NT, KS, false, true>(p, st) : pwr_launch2<T, NT, KS, false, false>(p, st);
+}
+
+template <typename T, int NT>
+static int pwr_launch_ks(const ConvP& p, int ks, bool two, bool geo, hipStream_t st) {
+  switch (ks) {
+    case 1: return pwr_launch<T, NT, 1>(p, two, geo, st);
+    case 2: return pwr_launch<T, NT, 2>(p, two, geo, st);
+    case 3: return pwr_launch<T, NT, 3>(p, two, geo, st);
+    case 4: if constexpr (NT <= 4) return pwr_launch<T, NT, 4>(p, two, geo, st); else return 0;
+  }
+  return 0;
+}
+
+template <typename T>
+static int dispatch_pwr(ConvP p, int ngroup, hipStream_t st) {
+  const long M = (long)p.B * p.Ho * p.Wo;
+  if (sizeof(T) != 2) return 0;  // f16 throughput mode only (an f32 fragment is twice the registers)
+  if (p.k != 1 || p.stride != 1 || ngroup != 1 || M < tune().pwr_m || !p.vec_store || M >= (1L << 27)) return 0;
+  const int ntp = conv_nt(p.Cout);
+  if (conv_cout_pad(p.Cout) != 16 * ntp) return 0;  // one channel tile covers Cout (Cout <= 128)
+  const int ks = (p.srcC[0] + 31) / 32 + (p.nsrc == 2 ? (p.srcC[1] + 31) / 32 : 0);
+  if (ks * ntp > tune().pwr_frags || ks > 4) return 0;
+  for (int s2 = 0; s2 < p.nsrc; ++s2) {
+    const int up = p.srcUp[s2];
+    const long npix = (long)p.B * (p.H >> up) * (p.W >> up);
+    const long bytes = ((npix - 1) * p.srcCs[s2] + p.srcC[s2]) * (long)sizeof(T);
+    if (bytes >= (1L << 31)) return 0;
+    p.srcBytes[s2] = (unsigned)bytes;
+  }
+  p.ntile = (M + 15) / 16;
+  p.NTpack = ntp;
+  const bool two = p.nsrc == 2, geo = p.addz != nullptr || p.srcUp[0] || (two && p.srcUp[1]);
+  if constexpr (sizeof(T) == 2) {
+    switch (ntp) {
+      case 1: return pwr_launch_ks<T, 1>(p, ks, two, geo, st);
+      case 2: return pwr_launch_ks<T, 2>(p, ks, two, geo, st);
+      case 4: return pwr_launch_ks<T, 4>(p, ks, two, geo, st);
+      case 5: return pwr_launch_ks<T, 5>(p, ks, two, geo, st);
+      case 8: return pwr_launch_ks<T, 8>(p, ks, two, geo, st);
+    }
+  }
+  return 0;
+}
+
 template <typename T>
 static int dispatch_pw(ConvP p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
@@ -1118,6 +1340,7 @@ static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
   int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), (size_t)tune().ws_budget);
   if (!nt) nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 156 * 1024);
   if (!nt) return 0;
+  if (p.k == 3 && nt < tune().ws_k3_minnt && nt < conv_nt(p.Cout)) return 0;
   p.NTpack = conv_nt(p.Cout);
   p.LSw = ws_ls(p.Kpad);
   p.Ctot = 0; p.nsteps = 0;
@@ -1158,6 +1381,8 @@ template <typename T>
 static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   const int pw = dispatch_pw<T>(p, ngroup, st);
   if (pw != 0) return pw < 0 ? pw : EY_OK;
+  const int pwr = dispatch_pwr<T>(p, ngroup, st);
+  if (pwr != 0) return pwr < 0 ? pwr : EY_OK;
   const int sm = dispatch_small<T>(p, ngroup, st);
   if (sm != 0) return sm < 0 ? sm : EY_OK;
   const int halo = dispatch_halo<T>(p, ngroup, st);
