@@ -681,6 +681,171 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// 3x3 tile kernel (single source, any Cin % 8 == 0, stride 1 or 2): the GEMM-shaped 3x3 convs (K = 9*Cin up to 2304) want a
+// big register tile per wave, which the weight-stationary kernel cannot give them (its [16*NT][K] weight tile must fit LDS,
+// so NT shrinks to 1-2 and every MFMA needs its own operand loads).  Here a 256-thread workgroup owns 8 output rows x 32
+// (stride 1) / 16 (stride 2) columns and 16*NT <= 64 output channels; a wave = 2 rows = MT (4 / 2) pixel blocks x NT channel
+// blocks, i.e. MT*NT MFMAs per MT + NT operand fragments.  K is walked in 32-channel chunks: the input halo of the chunk
+// goes to LDS once (range-checked buffer loads = zero padding; the next chunk's halo is already in flight in registers)
+// and is shared by all 9 taps and all waves; the weight fragments come straight from the L2-resident packed array by
+// scalar-offset buffer loads (one instruction each, double-buffered per tap) -- no weight staging, no weight LDS, so
+// several workgroups fit a CU and hide each other's latencies.  Stride 2 stores the halo split by column parity so that
+// fragment reads stay at the conflict-free odd 16-byte pixel stride.
+// WLDS: the chunk's [9 taps][16*NT rows][32 channels] weight block is staged into LDS next to the halo (one global read per
+// workgroup instead of one per wave: measured, the per-wave weight fragment loads saturate the CU's 64 B/clk vector-memory
+// path long before the MFMA pipe; LDS delivers 256 B/clk) -- at the price of 46 KB more LDS per workgroup.
+template <typename T, int NT, int S, bool WLDS>
+__global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TR = 8, MTC = (S == 1) ? 2 : 1, TC = 16 * MTC, MT = 2 * MTC;
+  constexpr int HR = (TR - 1) * S + 3, HC = (TC - 1) * S + 3, HCH = (HC + 1) / 2, CC = 32, CP = CC + 8;
+  constexpr int LROW = (S == 1) ? HC : 2 * HCH;            // LDS pixels per halo row
+  constexpr int NHV = (HR * HC * (CC / 8) + 255) / 256;    // halo vectors per thread
+  constexpr int NWVEC = 9 * 16 * NT * (CC / 8), NWV = WLDS ? (NWVEC + 255) / 256 : 1;  // weight vectors per chunk / per thread
+  T* hl = reinterpret_cast<T*>(smem);                      // [HR][LROW][CP]
+  T* wl = hl + HR * LROW * CP;                             // [9][16*NT][CP]   (WLDS)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.z, n_base = blockIdx.y * (16 * NT);
+  const int tilesX = (p.Wo + TC - 1) / TC, tilesY = (p.Ho + TR - 1) / TR, tiles_img = tilesX * tilesY;
+  const int b = blockIdx.x / tiles_img, trem = blockIdx.x - b * tiles_img;
+  const int oy0 = (trem / tilesX) * TR, ox0 = (trem % tilesX) * TC;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int Cin = p.srcC[0];
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
+  const __amdgpu_buffer_rsrc_t rw = ey_rsrc((const T*)p.w + (long)min(grp, p.wGmax) * p.wG + (long)n_base * p.Kpad, (unsigned)(16 * NT * p.Kpad * (int)sizeof(T)));
+  const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * (int)sizeof(T));
+  const int rowblk = 16 * p.Kpad * (int)sizeof(T);
+
+  // this thread's halo vectors: global byte offset (chunk 0) or OOB, and LDS element offset (tile independent)
+  unsigned hgo[NHV];
+  int hlo[NHV];
+  int hcv[NHV];
+#pragma unroll
+  for (int u = 0; u < NHV; ++u) {
+    const int v = threadIdx.x + u * 256;
+    const int px = v >> 2, cv = v & 3, hy = px / HC, hx = px - hy * HC;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = v < HR * HC * 4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    hgo[u] = ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.srcCs[0] + cv * 8) * (int)sizeof(T)) : EY_OOB;
+    const int lpix = (S == 1) ? hy * LROW + hx : hy * LROW + (hx & 1) * HCH + (hx >> 1);
+    hlo[u] = v < HR * HC * 4 ? lpix * CP + cv * 8 : -1;
+    hcv[u] = cv * 8;
+  }
+  auto issue_halo = [&](int c0, Vec8<T> (&hv)[NHV]) {
+#pragma unroll
+    for (int u = 0; u < NHV; ++u) BufLoad8<T>::load(hv[u], rs, (c0 + hcv[u]) < Cin ? hgo[u] : EY_OOB, c0 * (int)sizeof(T));
+  };
+  // fragment base of this lane in the halo: wave owns output rows 2*wave, 2*wave+1; block mt = (row mt/MTC, column block mt%MTC)
+  int bbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = 2 * wave + mt / MTC, col = (mt % MTC) * 16 + r;
+    bbase[mt] = ((S == 1) ? (row * LROW + col) : (row * 2 * LROW + col)) * CP + 8 * g;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
+
+  Vec8<T> hv[NHV];
+  issue_halo(0, hv);
+  if constexpr (WLDS) {
+    // this thread's weight vectors of a chunk: vector v = ((tap*16NT + row)*4 + cv)
+    unsigned wgo[NWV];
+#pragma unroll
+    for (int u = 0; u < NWV; ++u) {
+      const int v = threadIdx.x + u * 256, cv = v & 3, rt = v >> 2, tap = rt / (16 * NT), row = rt - tap * (16 * NT);
+      wgo[u] = v < NWVEC ? (unsigned)((row * p.Kpad + tap * Cin + cv * 8) * (int)sizeof(T)) : EY_OOB;
+    }
+    Vec8<T> wv[NWV];
+    auto issue_w = [&](int c0) {
+#pragma unroll
+      for (int u = 0; u < NWV; ++u) BufLoad8<T>::load(wv[u], rw, wgo[u], c0 * (int)sizeof(T));
+    };
+    issue_w(0);
+    const T* wlane = wl + r * CP + 8 * g;
+    for (int c0 = 0; c0 < Cin; c0 += CC) {
+      __syncthreads();  // every wave finished reading the previous chunk's halo and weights
+#pragma unroll
+      for (int u = 0; u < NHV; ++u)
+        if (hlo[u] >= 0) hv[u].store(hl + hlo[u]);
+#pragma unroll
+      for (int u = 0; u < NWV; ++u) {
+        const int v = threadIdx.x + u * 256;
+        if (v < NWVEC) wv[u].store(wl + (v >> 2) * CP + (v & 3) * 8);
+      }
+      __syncthreads();
+      if (c0 + CC < Cin) {  // next chunk: in flight during the 9 taps below
+        issue_halo(c0 + CC, hv);
+        issue_w(c0 + CC);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        const int toff = ((S == 1) ? (ky * LROW + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
+        Vec8<T> bf[MT], a[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) a[nt].load(wlane + (tap * 16 * NT + nt * 16) * CP);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) bf[mt].load(hl + bbase[mt] + toff);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(a[nt], bf[mt], acc[mt][nt]);
+      }
+    }
+  } else {
+  // weight fragments straight from L2: ring of 4 tap buffers, 3 taps ahead of the MFMAs
+  Vec8<T> af[4][NT];
+  auto load_w = [&](int tap, int c0, Vec8<T> (&a)[NT]) {
+    const int kofs = (tap * Cin + c0) * (int)sizeof(T);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(a[nt], rw, wvoff, nt * rowblk + kofs);
+  };
+  load_w(0, 0, af[0]);
+  load_w(1, 0, af[1]);
+  load_w(2, 0, af[2]);
+  for (int c0 = 0; c0 < Cin; c0 += CC) {
+    __syncthreads();  // every wave finished reading the previous chunk's halo
+#pragma unroll
+    for (int u = 0; u < NHV; ++u)
+      if (hlo[u] >= 0) hv[u].store(hl + hlo[u]);
+    __syncthreads();
+    const bool more = c0 + CC < Cin;
+    if (more) issue_halo(c0 + CC, hv);  // in flight during the 9 taps below
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      if (tap + 3 < 9) load_w(tap + 3, c0, af[(tap + 3) & 3]);
+      else if (more) load_w(tap + 3 - 9, c0 + CC, af[(tap + 3) & 3]);
+      const int toff = ((S == 1) ? (ky * LROW + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
+      Vec8<T> bf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bf[mt].load(hl + bbase[mt] + toff);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[tap & 3][nt], bf[mt], acc[mt][nt]);
+    }
+    // 9 taps per chunk: the next chunk's taps 0,1,2 sit in buffers 1,2,3 -> rotate so that every chunk starts on buffer 0
+    if (more) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { af[0][nt] = af[1][nt]; af[1][nt] = af[2][nt]; af[2][nt] = af[3][nt]; }
+    }
+  }
+  }
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int oy = oy0 + 2 * wave + mt / MTC, ox = ox0 + (mt % MTC) * 16 + r;
+    if (oy < p.Ho && ox < p.Wo) conv_epilogue<T, NT>(p, acc[mt], ((long)b * p.Ho + oy) * p.Wo + ox, b, oy, ox, ch0, grp);
+  }
+}
+
+// ================================================================================================================
 // Lean pointwise kernel (1x1, stride 1, <= 2 sources) for maps up to ~80x80.  Measured on MI355X (tools/micro): a lone
 // wave retires about one instruction per 2.5 ns and a kernel launch costs 1.6 us, so for layers that move a few MB the
 // run time is the per-wave instruction count plus the memory round trips, not bandwidth.  Hence: no LDS, no barrier,
@@ -995,13 +1160,23 @@ struct EyTune {
   long ws_budget = ey_env("EY_WS_LDS_KB", 76) << 10;  // ws: preferred LDS per workgroup (2 workgroups per CU)
   long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
   long ws_k3_minnt = ey_env("EY_WS_K3_MINNT", 0);     // 3x3: use the K-chunked kernel when the weight-stationary tile would cover fewer than this many 16-channel blocks (and not all of Cout)
+  long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
+  long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 128); // tile kernel for stride 2 only from this many input channels ...
+  long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
+  long tile_mink = ey_env("EY_TILE_MINK", 0);         // 3x3 tile kernel for K = 9*Cin >= this (huge value = off)
   long pwr_m = ey_env("EY_PWR_M", 110000);            // register-stationary pointwise kernel from this many output pixels (huge value = off)
-  long pwr_frags = ey_env("EY_PWR_FRAGS", 16);        // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
+  long pwr_frags = ey_env("EY_PWR_FRAGS", 24);        // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
   long pw_m = ey_env("EY_PW_M", 110000);              // lean pointwise kernel below this many output pixels (0 = off)
   long pw_waves = ey_env("EY_PW_WAVES", 3072);        // pw: prefer the widest channel tile that still leaves this many waves
   long pw_wbytes = ey_env("EY_PW_WMB", 64) << 20;     // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this
 };
 static const EyTune& tune() { static EyTune t; return t; }
+// kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels); defined in the f16 translation unit
+#if EY_CONV_PART == 16
+thread_local int g_last_variant = 0;
+#else
+extern thread_local int g_last_variant;
+#endif
 // ---- weight-stationary dispatch
 static int ws_ls(int Kpad) { return Kpad; }  // conv_kpad() already makes the row an odd number of 16-byte (f16) units
 static const int WS_NT[5] = {8, 5, 4, 2, 1};
@@ -1143,6 +1318,48 @@ static int dispatch_halo(ConvP p, int ngroup, hipStream_t st) {
   return 0;
 }
 
+// ---- 3x3 tile dispatch
+template <typename T, int NT, int S>
+static int tile_launch(ConvP p, int ngroup, hipStream_t st) {
+  constexpr int TR = 8, TC = (S == 1) ? 32 : 16, HR = (TR - 1) * S + 3, HC = (TC - 1) * S + 3, LROW = (S == 1) ? HC : 2 * ((HC + 1) / 2);
+  const bool wlds = tune().tile_wlds == 1 || (tune().tile_wlds == 2 && S == 1);
+  const size_t lds = ((size_t)HR * LROW + (wlds ? 9 * 16 * NT : 0)) * 40 * sizeof(T);
+  const long tiles = (long)p.B * ((p.Wo + TC - 1) / TC) * ((p.Ho + TR - 1) / TR);
+  const dim3 grid((unsigned)tiles, (unsigned)(conv_cout_pad(p.Cout) / (16 * NT)), (unsigned)ngroup);
+  static bool attr = false;
+  if (!attr) {  // up to 46 + 46 KB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)conv3_tile_kernel<T, NT, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    attr = true;
+  }
+  if (wlds) hipLaunchKernelGGL((conv3_tile_kernel<T, NT, S, true>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv3_tile_kernel<T, NT, S, false>), grid, dim3(256), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(tile): %s", hipGetErrorString(e_));
+  g_last_variant = 6000 + NT * 10 + S;
+  return 1;
+}
+
+template <typename T>
+static int dispatch_tile(ConvP p, int ngroup, hipStream_t st) {
+  if (sizeof(T) != 2) return 0;  // f16 throughput mode (the f32 parity mode keeps the exact-f32 kernels below)
+  if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || 9L * p.srcC[0] < tune().tile_mink) return 0;
+  if (p.stride == 2 && (p.srcC[0] < tune().tile_s2_minc || (long)p.B * p.Ho * p.Wo < tune().tile_s2_minm)) return 0;
+  const int ntp = conv_nt(p.Cout);
+  const int nt = ntp % 4 == 0 ? 4 : ntp == 2 ? 2 : ntp == 1 ? 1 : 0;
+  if (!nt) return 0;
+  const long npix = (long)p.B * p.H * p.W;
+  const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * (long)sizeof(T);
+  if (bytes >= (1L << 31) || p.srcG * (long)sizeof(T) * (ngroup - 1) >= (1L << 31)) return 0;
+  if ((long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) >= (1L << 31)) return 0;
+  p.srcBytes[0] = (unsigned)bytes;
+  p.NTpack = ntp;
+  if constexpr (sizeof(T) == 2) {
+    if (p.stride == 1) return nt == 4 ? tile_launch<T, 4, 1>(p, ngroup, st) : nt == 2 ? tile_launch<T, 2, 1>(p, ngroup, st) : tile_launch<T, 1, 1>(p, ngroup, st);
+    return nt == 4 ? tile_launch<T, 4, 2>(p, ngroup, st) : nt == 2 ? tile_launch<T, 2, 2>(p, ngroup, st) : tile_launch<T, 1, 2>(p, ngroup, st);
+  }
+  return 0;
+}
+
 // ---- small-M dispatch
 template <typename T, int NT>
 static int small_launch(ConvP p, int ngroup, hipStream_t st) {
@@ -1200,12 +1417,6 @@ static int dispatch_small(ConvP p, int ngroup, hipStream_t st) {
 }
 
 // ---- lean pointwise dispatch
-// kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels); defined in the f16 translation unit
-#if EY_CONV_PART == 16
-thread_local int g_last_variant = 0;
-#else
-extern thread_local int g_last_variant;
-#endif
 
 static int pw_pick_nt(int Cout, long mtiles, int es) {
   const int ntp = conv_nt(Cout), rows = conv_cout_pad(Cout) / 16;
@@ -1385,6 +1596,8 @@ static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   if (pwr != 0) return pwr < 0 ? pwr : EY_OK;
   const int sm = dispatch_small<T>(p, ngroup, st);
   if (sm != 0) return sm < 0 ? sm : EY_OK;
+  const int tl = dispatch_tile<T>(p, ngroup, st);
+  if (tl != 0) return tl < 0 ? tl : EY_OK;
   const int halo = dispatch_halo<T>(p, ngroup, st);
   if (halo != 0) return halo < 0 ? halo : EY_OK;
   const int ws = dispatch_ws<T>(p, ngroup, st);

@@ -184,3 +184,24 @@ def test_no_cpu_fallback(M):
     m = M.Conv(16, 16, 1)
     with pytest.raises(HipLibraryError):
         m.eval()(torch.zeros(1, 16, 4, 4))
+
+
+@pytest.mark.parametrize("c1,c2,k,s,h,w", [
+    (128, 128, 3, 2, 40, 36), (128, 256, 3, 2, 20, 20), (256, 64, 3, 1, 20, 20), (128, 64, 3, 1, 24, 40), (64, 64, 3, 1, 41, 37), (64, 64, 3, 2, 33, 47),
+    (16, 8, 3, 1, 30, 30), (32, 16, 3, 1, 17, 33), (64, 32, 3, 1, 10, 10), (16, 32, 3, 2, 64, 48), (32, 32, 1, 1, 176, 160), (48, 64, 1, 1, 176, 160),
+    (96, 128, 1, 1, 176, 160), (80, 80, 1, 1, 176, 160), (64, 80, 1, 1, 90, 70), (256, 256, 1, 1, 20, 20), (128, 64, 1, 1, 20, 20), (384, 256, 1, 1, 20, 20)])
+def test_conv_f16_kernels_agree_with_exact_f32_kernels(M, c1, c2, k, s, h, w):
+    """The f16 throughput mode dispatches to different kernels (3x3 tile, lean / register-stationary pointwise) than the f32
+    parity mode.  On the SAME f16-representable weights and inputs both accumulate exact products in fp32, so they may differ
+    only by summation order and the final f16 rounding: a tight check of the f16-only kernels' indexing at sizes that reach them."""
+    torch.manual_seed(c1 * 31 + c2)
+    m = M.Conv(c1, c2, k, s)
+    load_synth(m, "cvx")
+    m.fuse_bn()
+    with torch.no_grad():
+        m.conv.weight.copy_(m.conv.weight.half().float())
+    x = (torch.rand(4, c1, h, w) - 0.5).half()
+    want = to_dev(m, torch.float32)(x.float().cuda()).float().cpu()
+    got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * scale)

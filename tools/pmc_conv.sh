@@ -1,0 +1,9 @@
+#!/bin/bash
+# Developer tool (GPU box): SQ counters of single conv shapes.  usage: tools/pmc_conv.sh <tag> "<ENV=..>" shape [shape...]
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=$1; envs=$2; shift 2
+cd /tmp && export TMPDIR=/tmp
+[ -n "$envs" ] && export $envs
+C="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+timeout -k 10 200 rocprofv3 --pmc $C -d $R/gpurun_out/pmc_$tag -o p --output-format csv -- python $R/tools/conv_bench.py 5 "$@" > $R/gpurun_out/pmc_$tag.log 2>&1
+python3 $R/tools/pmc_summary.py $R/gpurun_out/pmc_$tag/p_counter_collection.csv
