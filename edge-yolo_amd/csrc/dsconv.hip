@@ -204,6 +204,151 @@ __global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
   }
 }
 
+// ================================================================================================================
+// Register-strip variant (f16 throughput mode): NO activation LDS, no barriers after the weight staging.
+// A lane owns a strip of P=4 consecutive output pixels x 8 channels; lane = (strip r of 16, channel group g of 4), i.e. a
+// wave covers 16 strips x 32 channels per channel step.  The depthwise stencil runs row by row out of registers: K+P-1
+// range-checked 16-byte buffer loads per input row (zero padding for free), each loaded vector feeding up to K*... outputs,
+// fp32 accumulation, depthwise weights broadcast from a few KB of LDS.  The rounded f16 result of (pixel, 8 channels) in
+// lane (r, g) IS the MFMA B fragment of the pointwise GEMM (k = 32 channels per step, column = pixel), so the 1x1 conv
+// follows directly from registers against register-resident packed pw weights; epilogue = bias, SiLU, residual, wide store.
+template <int K, int NT, int KS, int P>
+__global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef f16 T;
+  constexpr int NX = P + K - 1;
+  T* s_wdw = reinterpret_cast<T*>(smem);  // [K*K][C]
+  const int C = p.Cin;
+  for (int v = threadIdx.x; v < K * K * (C >> 3); v += 256) {
+    Vec8<T> t;
+    t.load((const T*)p.wdw + v * 8);
+    t.store(s_wdw + v * 8);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int WS = (p.W + P - 1) / P;
+  const int nstrip = p.B * p.H * WS;
+  const int strip = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + r;  // (WS below uses the template P)
+  const bool sv = strip < nstrip;
+  int b = 0, oy = 0, x0 = 0;
+  if (sv) {
+    const int t = strip / WS;
+    x0 = (strip - t * WS) * P;
+    b = t / p.H;
+    oy = t - b * p.H;
+  }
+  if ((blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 >= nstrip) return;  // whole wave beyond the image
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(p.x, p.xBytes);
+  // pointwise weights -> registers
+  Vec8<T> af[KS][NT];
+  {
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(p.wpw, (unsigned)(16 * NT * p.Kpad * (int)sizeof(T)));
+    const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * (int)sizeof(T));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[ks][nt], rw, wvoff, (nt * 16 * p.Kpad + ks * 32) * (int)sizeof(T));
+  }
+  Vec8<T> bf[KS][P];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int cb = ks * 32 + 8 * g;       // this lane's 8 channels in this step
+    const bool cok = cb < C;              // lanes beyond C carry zeros into the MFMA
+    float acc[P][8];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[q][i] = (p.dwbias && cok) ? p.dwbias[cb + i] : 0.f;
+    // one input row at a time (rolled loop: only two rows of vectors are ever live), the next row's loads in flight
+    auto load_row = [&](int ky, Vec8<T> (&xr)[NX]) {
+      const int iy = oy - K / 2 + ky;
+      const bool yok = sv && cok && iy >= 0 && iy < p.H;
+      const int rowoff = ((b * p.H + iy) * p.W + x0 - K / 2) * p.xCs + cb;
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int ix = x0 - K / 2 + j;
+        BufLoad8<T>::load(xr[j], rx, (yok && ix >= 0 && ix < p.W) ? (unsigned)((rowoff + j * p.xCs) * (int)sizeof(T)) : EY_OOB);
+      }
+    };
+    Vec8<T> xin[NX], xnx[NX];
+    load_row(0, xin);
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      if (ky + 1 < K) load_row(ky + 1, xnx);
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        Vec8<T> w;
+        if (cok) w.load(s_wdw + (ky * K + kx) * C + cb);
+        else w.zero();
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xin[q + kx].get(i), w.get(i), acc[q][i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NX; ++j) xin[j] = xnx[j];
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bf[ks][q].set(i, cok ? ey_act(acc[q][i], p.dwact) : 0.f);
+  }
+  // ---- pointwise GEMM + epilogue, one pixel block (16 strips' q-th pixel) at a time
+  const int ch0 = g * 4 * NT;  // NT == NTpack: lane owns channels ch0 .. ch0 + 4NT of its pixel
+  float bias[4 * NT];
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) bias[i] = (p.bias && ch0 + i < p.Cout) ? p.bias[ch0 + i] : 0.f;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    f32x4 pacc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) pacc[nt] = (f32x4)0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pacc[nt] = ds_mma16(af[ks][nt], bf[ks][q], pacc[nt]);
+    const int ox = x0 + q;
+    if (!sv || ox >= p.W) continue;
+    const long m = ((long)b * p.H + oy) * p.W + ox;
+    float v[4 * NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * nt + j] = ey_act(pacc[nt][j] + bias[4 * nt + j], p.act);
+    T* yp = (T*)p.y + m * p.yCs + ch0;
+    const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
+    if (NT % 2 == 0 && p.vec_store > 1 && ch0 + 4 * NT <= p.Cout) {
+#pragma unroll
+      for (int h = 0; h < NT / 2; ++h) {
+        if (rp) {
+          Vec8<T> rr;
+          rr.load(rp + 8 * h);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[8 * h + j] += rr.get(j);
+        }
+        Vec8<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.set(j, v[8 * h + j]);
+        o.store(yp + 8 * h);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) {
+        if (ch0 + 4 * h + 4 <= p.Cout) {
+          float o[4] = {v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+          if (rp) {
+            const f16x4 rr = *reinterpret_cast<const f16x4*>(rp + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += (float)rr[j];
+          }
+          const f16x4 ov = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+          *reinterpret_cast<f16x4*>(yp + 4 * h) = ov;
+        }
+      }
+    }
+  }
+}
+
 // mirrors conv_igemm.hip (same packing rule)
 static int ds_conv_nt(int Cout) {
   if (Cout <= 16) return 1;
@@ -265,6 +410,52 @@ static int ds_launch_k(const DsP& p, int k, hipStream_t st) {
   return ds_launch_nt<T, 7>(p, st);
 }
 
+// ---- register-strip dispatch: f16, Cout <= 64 covered by ONE channel tile (NT = NTpack), Cin <= 64, 4-element vector stores
+#include <stdlib.h>
+// strip length P: long strips reuse every loaded vector for more outputs, short strips give small maps enough waves
+// (a 20x20x32 map is 800 waves of 16 pixels; the per-wave instruction stream, not bandwidth, sets the time there)
+template <int K, int NT, int KS, int P>
+static int ds_strip_launch(const DsP& p, hipStream_t st) {
+  const long nstrip = (long)p.B * p.H * ((p.W + P - 1) / P);
+  const long nwave = (nstrip + 15) / 16;
+  const size_t lds = (size_t)K * K * p.Cin * sizeof(f16);
+  hipLaunchKernelGGL((dsconv_strip_kernel<K, NT, KS, P>), dim3((unsigned)((nwave + 3) / 4)), dim3(256), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_dsconv(strip): %s", hipGetErrorString(e_));
+  return 1;
+}
+static long ds_env(const char* n, long d) { const char* v = getenv(n); return v && *v ? atol(v) : d; }
+template <int K, int NT, int KS>
+static int ds_strip_p(const DsP& p, hipStream_t st) {
+  // measured on MI355X (tools/ds_bench.py): k=7 wants the long strip (49 taps: reuse of loaded vectors dominates), k=3/5 the
+  // short ones (more waves; the per-wave instruction stream sets the time), 2-pixel strips once a 64-channel map has >= 40k pixels
+  static const long force = ds_env("EY_DS_P", 0);
+  const long px = (long)p.B * p.H * p.W;
+  int P = K == 7 ? 4 : (p.Cin >= 64 && px >= 40000) ? 2 : 1;
+  if (force) P = (int)force;
+  if (P == 4) return ds_strip_launch<K, NT, KS, 4>(p, st);
+  if (P == 2) return ds_strip_launch<K, NT, KS, 2>(p, st);
+  return ds_strip_launch<K, NT, KS, 1>(p, st);
+}
+template <int K>
+static int ds_strip_k(const DsP& p, int nt, int ks, hipStream_t st) {
+#define DSS(NTV, KSV) if (nt == NTV && ks == KSV) return ds_strip_p<K, NTV, KSV>(p, st);
+  DSS(1, 1) DSS(2, 1) DSS(4, 2)
+#undef DSS
+  return 0;
+}
+static int ds_strip_dispatch(const DsP& p, int k, hipStream_t st) {
+  static const bool off = [] { const char* v = getenv("EY_DS_STRIP"); return v && *v == '0'; }();
+  if (off) return 0;
+  const int nt = p.NTpack, ks = (p.Cin + 31) / 32;
+  if (p.Cout > 16 * nt || ks > 2 || !p.vec_store || p.Cout % 4) return 0;
+  if (p.Cin < 32) return 0;  // 16 channels would leave half of every wave's lanes (channel groups 2,3) idle: the LDS-tile kernel wins
+  if ((long)p.B * p.H * p.W >= (1L << 29)) return 0;
+  if (k == 3) return ds_strip_k<3>(p, nt, ks, st);
+  if (k == 5) return ds_strip_k<5>(p, nt, ks, st);
+  return ds_strip_k<7>(p, nt, ks, st);
+}
+
 extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,
                          const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream) {
   EY_CHECK(x && w_dw_kkc && w_pw_packed && y, "dsconv: null pointer");
@@ -291,5 +482,9 @@ extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int 
   p.vec_store = Cout % 4 == 0 && (y_cstride * es) % va == 0 && ey_aligned(y, va) && (!res || ((res_cstride * es) % va == 0 && ey_aligned(res, va)));
   if (p.vec_store && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16) && (!res || ((res_cstride * es) % 16 == 0 && ey_aligned(res, 16)))) p.vec_store = 2;
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == EY_F16) {
+    const int rs = ds_strip_dispatch(p, k, st);
+    if (rs != 0) return rs < 0 ? rs : EY_OK;
+  }
   return dtype == EY_F16 ? ds_launch_k<f16>(p, k, st) : ds_launch_k<float>(p, k, st);
 }

@@ -206,9 +206,76 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int B, int H, int W, int C,
   o.store(y + m * yCs + c8);
 }
 
+// 3x3 strip variant (the DWConv of the detection heads): a thread owns P consecutive output pixels x 8 channels.  The
+// 3 x (P+2) input vectors come by range-checked buffer loads (zero padding without branches, all in flight at once), the 9
+// weight vectors and the bias live in registers, and every loaded vector feeds up to 3 outputs per row: 18 loads and
+// (for f16) 288 v_fma_mix per 4 outputs instead of 36 loads + per-tap address arithmetic + 72 conversions per output.
+template <typename T, int P>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(int B, int H, int W, int C, int act, const T* __restrict__ x, int xCs, unsigned xBytes,
+                                                            const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int yCs) {
+  const int cv = C >> 3, WS = (W + P - 1) / P;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= B * H * WS * cv) return;
+  const int c8 = (idx % cv) * 8;
+  int t = idx / cv;
+  const int x0 = (t % WS) * P;
+  t /= WS;
+  const int oy = t % H, b = t / H;
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(x, xBytes);
+  Vec8<T> xin[3][P + 2];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy - 1 + ky;
+    const bool yok = iy >= 0 && iy < H;
+    const int rowoff = ((b * H + iy) * W + x0 - 1) * xCs + c8;
+#pragma unroll
+    for (int j = 0; j < P + 2; ++j) {
+      const int ix = x0 - 1 + j;
+      BufLoad8<T>::load(xin[ky][j], rx, (yok && ix >= 0 && ix < W) ? (unsigned)((rowoff + j * xCs) * (int)sizeof(T)) : EY_OOB);
+    }
+  }
+  Vec8<T> wv[9];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) wv[tp].load(w + tp * C + c8);
+  float acc[P][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float bb = bias ? bias[c8 + i] : 0.f;
+#pragma unroll
+    for (int q = 0; q < P; ++q) acc[q][i] = bb;
+  }
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xin[ky][q + kx].get(i), wv[ky * 3 + kx].get(i), acc[q][i]);
+  T* yp = y + (long)((b * H + oy) * W + x0) * yCs + c8;
+#pragma unroll
+  for (int q = 0; q < P; ++q) {
+    if (x0 + q < W) {
+      Vec8<T> o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o.set(i, ey_act(acc[q][i], act));
+      o.store(yp + (long)q * yCs);
+    }
+  }
+}
+
 template <typename T>
 static int dw_launch(int B, int H, int W, int C, int k, int act, const void* x, int xCs, const void* w, const float* bias, void* y, int yCs, hipStream_t st) {
   const long total = (long)B * H * W * (C / 8);
+  const long xbytes = (((long)B * H * W - 1) * xCs + C) * (long)sizeof(T);
+  if (k == 3 && xbytes < (1L << 31) && total < (1L << 31)) {
+    constexpr int P = sizeof(T) == 2 ? 4 : 2;
+    const long n = (long)B * H * ((W + P - 1) / P) * (C / 8);
+    hipLaunchKernelGGL((dwconv3_strip_kernel<T, P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, H, W, C, act, (const T*)x, xCs, (unsigned)xbytes,
+                       (const T*)w, bias, (T*)y, yCs);
+    EY_LAUNCH_CHECK("ey_dwconv");
+    return EY_OK;
+  }
   dim3 grid((unsigned)((total + 255) / 256));
 #define DW(K) hipLaunchKernelGGL((dwconv_kernel<T, K>), grid, dim3(256), 0, st, B, H, W, C, act, (const T*)x, xCs, (const T*)w, bias, (T*)y, yCs)
   if (k == 3) DW(3); else if (k == 5) DW(5); else DW(7);

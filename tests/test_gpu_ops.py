@@ -205,3 +205,20 @@ def test_conv_f16_kernels_agree_with_exact_f32_kernels(M, c1, c2, k, s, h, w):
     got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
     scale = float(want.abs().max())
     torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("c,k,h,w", [(16, 3, 40, 36), (16, 7, 40, 40), (32, 3, 21, 19), (32, 5, 20, 20), (32, 7, 33, 30), (64, 3, 20, 20), (64, 5, 20, 20), (64, 7, 22, 25)])
+def test_dsconv_f16_kernel_agrees_with_exact_f32_kernel(M, c, k, h, w):
+    """f16 mode runs the register-strip DSConv kernel, f32 mode the LDS-tile kernel; same f16-representable weights and inputs ->
+    they may differ only by fp32 summation order, the f16 rounding of the depthwise intermediate and of the output."""
+    torch.manual_seed(c * 7 + k)
+    m = M.DSConv(c, c, k)
+    load_synth(m, "dsx")
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(prm.half().float())
+    x = (torch.rand(3, c, h, w) - 0.5).half()
+    want = to_dev(m, torch.float32)(x.float().cuda()).float().cpu()
+    got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got, want, rtol=4e-3, atol=4e-3 * scale)
