@@ -51,6 +51,23 @@ def trace():
         _ops.TRACE = None
 
 
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/*_pmc_traffic.json, written by
+    tools/round_profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs with the guide's gfx950 correction), or None."""
+    import glob
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
+
+
 def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
     step_fn()
     torch.cuda.synchronize()
@@ -74,7 +91,11 @@ def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
         out.update({"bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(ach / hbm_peak_gbs, 4)})
     out["alg_bytes_per_launch"] = int(bytes_per)
     out["alg_flops_per_launch"] = int(flops_per)
-    out["traffic"] = None  # HBM bytes from PMC counters: collected offline (profiles/), see DESIGN.md
+    # HBM bytes per launch from PMC counters: they need their own rocprofv3 passes, so the number comes from the committed
+    # summary of the newest pass over this same bench command (null when that pass did not see this kernel)
+    out["traffic"], src = _pmc_traffic(name)
+    if src:
+        out["traffic_source"] = "profiles/" + src
     out["top5"] = [{"kernel": k, "ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps}
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:5]]
     return out

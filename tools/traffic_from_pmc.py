@@ -1,0 +1,75 @@
+"""Developer tool: per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py ->
+profiles/<tag>_pmc_traffic.json, keyed by the kernel labels bench.py's `roofline` uses.
+usage: traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+
+Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are KB per dispatch (derived from
+TCC_EA0_RDREQ / WRREQ); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads,
+so it is doubled here (all heavy kernels of this path read with 16-byte buffer/global loads); WRITE_SIZE is exact for
+16-byte stores.  Infinity-Cache hits are counted, i.e. this is traffic at the L2's memory side, not DRAM-only."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def label_of(name):
+    m = re.search(r"conv_ws_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:
+        return f"conv_ws_kernel<f16,{m[1]},{m[2]},{m[3]}>"
+    m = re.search(r"conv_pwr_kernelIDF16_Li(\d+)ELi(\d+)E", name)
+    if m:
+        return f"conv_pwr_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv_pw_kernelIDF16_Li(\d+)E", name)
+    if m:
+        return f"conv_pw_kernel<f16,{m[1]}>"
+    m = re.search(r"conv3_tile_kernelIDF16_Li(\d+)ELi(\d+)E", name)
+    if m:
+        return f"conv3_tile_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv3_halo_kernelIDF16_Li(\d+)ELi(\d+)E", name)
+    if m:
+        return f"conv3_halo_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv_small_kernelIDF16_Li(\d+)ELi(\d+)E", name)
+    if m:
+        return f"conv_small_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"dsconv_kernelIDF16_Li(\d+)E", name) or re.search(r"dsconv_strip_kernel(?:ILi|<)(\d+)", name)
+    if m:
+        return f"dsconv_kernel<{m[1]}>"
+    m = re.search(r"dwconv_kernelIDF16_Li(\d+)E", name)
+    if m:
+        return f"dwconv_kernel<{m[1]}>"
+    if "dwconv3_strip" in name:
+        return "dwconv_kernel<3>"
+    for k in ("stem_kernel", "dwt_kernel", "head_decode_kernel", "linattn_kernel", "sppf_kernel", "copy_kernel", "softattn_kernel"):
+        if k in name:
+            return k
+    if "nms_" in name:
+        return "nms(score+sort_greedy)"
+    return None
+
+
+def per_kernel(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        lab = label_of(r["Kernel_Name"])
+        if lab:
+            agg[lab][0] += 1
+            agg[lab][1] += float(r["Counter_Value"])
+    return agg
+
+
+if __name__ == "__main__":
+    f, w = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for lab in sorted(set(f) | set(w)):
+        nf, kf = f.get(lab, [0, 0.0])
+        nw, kw = w.get(lab, [0, 0.0])
+        fetch = 2.0 * 1024 * kf / max(nf, 1)
+        write = 1024 * kw / max(nw, 1)
+        out[lab] = {"launches_profiled": nf, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+                    "hbm_bytes_per_launch": round(fetch + write), "fetch_kb_raw_avg": round(kf / max(nf, 1), 1)}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-pipeline; FETCH_SIZE doubled (gfx950 wide-read correction)",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    print(f"{len(out)} kernels -> {sys.argv[3]}")
