@@ -349,6 +349,141 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
   }
 }
 
+// ================================================================================================================
+// Toeplitz-MFMA variant for the wide depthwise kernels (k = 5, 7; f16 mode): 49 taps per output make the stencil VALU-bound
+// on the vector units (196 wave-level FMAs per channel per 256 pixels).  Along x a depthwise row filter is a banded matrix:
+//     out[c][y][x0+i] = sum_ky sum_k T_c,ky[i][k] * in[c][y+ky][x0+k],     T[i][k] = w[c][ky][k-i]  (0 <= k-i < K)
+// i.e. per channel and filter row ONE 16x16x32 MFMA (A = T, 16 outputs x 32 inputs; B = 32 input columns x 16 image rows)
+// instead of 16*16*K FMAs: 7 MFMAs per channel per 16x16 tile.  The k index of an MFMA operand must be register-contiguous,
+// so the halo tile is transposed to channel-major [c][row][x] on its way into LDS (8 ds_write_b16 per loaded vector); the A
+// fragments T_c,ky are precomputed on the host (ey_dsconv_pack_toeplitz) and live in registers: wave w owns channels w, w+8, ...
+// The MFMA result (lane = image row, 4 outputs along x) is written as f16 to a pixel-major LDS tile and the pointwise GEMM
+// runs from there exactly as in dsconv_kernel.  Persistent 512-thread workgroups, 2 barriers per tile, the next tile's halo
+// in flight during the pointwise phase.
+#define TZ_RS 24  // halo row stride (elements): 48 B -> the 16 rows a B fragment touches fall into distinct banks
+template <int K, int NT, int CPW>
+__global__ __launch_bounds__(512) void dsconv_tz_kernel(DsP p, const f16* __restrict__ tz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef f16 T;
+  constexpr int TH = 16, TW = 16, HH = TH + K - 1, HW = TW + K - 1, CPL = HH * TZ_RS;
+  constexpr int C = 8 * CPW;                       // channels (8 waves x CPW each)
+  constexpr int LSd = C + 8, ROWS = 16 * LSd + 8;  // s_dw: [row][x][LSd], rows padded so that column-of-rows writes spread over banks
+  constexpr int NVEC = HH * HW * (C / 8), NHV = (NVEC + 511) / 512;
+  T* s_in = reinterpret_cast<T*>(smem);            // [C][HH][TZ_RS]
+  T* s_dw = s_in + C * CPL + 32;                   // [16][ROWS]  (+32: B fragments of the last halo row read up to 16 B past a plane)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  for (int i = tid; i < (C * CPL + 32 + 16 * ROWS + 64) / 2; i += 512) reinterpret_cast<unsigned*>(smem)[i] = 0u;  // finite everywhere
+  // Toeplitz fragments of this wave's channels, pointwise weights, bias -> registers
+  Vec8<T> tzf[CPW][K];
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc)
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) tzf[cc][ky].load(tz + (((wave + 8 * cc) * K + ky) * 64 + lane) * 8);
+  Vec8<T> af[NT];
+  {
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(p.wpw, (unsigned)(16 * NT * p.Kpad * (int)sizeof(T)));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[nt], rw, (unsigned)((r * p.Kpad + 8 * g) * (int)sizeof(T)), nt * 16 * p.Kpad * (int)sizeof(T));
+  }
+  const int ch0 = g * 4 * NT;
+  float bias[4 * NT];
+#pragma unroll
+  for (int i = 0; i < 4 * NT; ++i) bias[i] = (p.bias && ch0 + i < p.Cout) ? p.bias[ch0 + i] : 0.f;
+  float dwb[CPW];
+#pragma unroll
+  for (int cc = 0; cc < CPW; ++cc) dwb[cc] = p.dwbias ? p.dwbias[wave + 8 * cc] : 0.f;
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(p.x, p.xBytes);
+  const int tiles_img = p.tilesX * p.tilesY;
+  // this thread's halo vectors (tile independent): channel group cv (slowest, so a wave writes consecutive pixels of one channel), pixel
+  int hpo[NHV], hlo[NHV];
+#pragma unroll
+  for (int u = 0; u < NHV; ++u) {
+    const int v = tid + u * 512, cv = v / (HH * HW), px = v - cv * (HH * HW), hy = px / HW, hx = px - hy * HW;
+    hpo[u] = v < NVEC ? ((hy << 8) | hx | (cv << 16)) : -1;
+    hlo[u] = (8 * cv) * CPL + hy * TZ_RS + hx;
+  }
+  auto issue_halo = [&](long tile, Vec8<T> (&hv)[NHV]) {
+    const int b = (int)(tile / tiles_img), trem = (int)(tile - (long)b * tiles_img);
+    const int iy0 = (trem / p.tilesX) * TH - K / 2, ix0 = (trem % p.tilesX) * TW - K / 2;
+#pragma unroll
+    for (int u = 0; u < NHV; ++u) {
+      const int hy = (hpo[u] >> 8) & 0xFF, hx = hpo[u] & 0xFF, cv = hpo[u] >> 16;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool ok = hpo[u] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      BufLoad8<T>::load(hv[u], rx, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.xCs + cv * 8) * (int)sizeof(T)) : EY_OOB);
+    }
+  };
+  Vec8<T> hv[NHV];
+  long tile = blockIdx.x;
+  if (tile < p.ntile) issue_halo(tile, hv);
+  __syncthreads();  // LDS zero fill complete
+  for (; tile < p.ntile; tile += gridDim.x) {
+    // ---- 1. halo -> LDS, transposed to [c][row][x]
+#pragma unroll
+    for (int u = 0; u < NHV; ++u) {
+      if (hpo[u] >= 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_in[hlo[u] + i * CPL] = hv[u].v[i];
+      }
+    }
+    __syncthreads();
+    // ---- 2. depthwise rows as Toeplitz MFMAs; result (lane = image row j, 4 outputs x = 4g..4g+3) -> s_dw[row][x][c]
+#pragma unroll
+    for (int cc = 0; cc < CPW; ++cc) {
+      const int c = wave + 8 * cc;
+      f32x4 acc = (f32x4)0.f;
+      const T* bp = s_in + c * CPL + r * TZ_RS + 8 * g;
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        Vec8<T> bfr;
+        bfr.load(bp + ky * TZ_RS);
+        acc = ds_mma16(tzf[cc][ky], bfr, acc);
+      }
+      T* dp = s_dw + r * ROWS + (4 * g) * LSd + c;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dp[t * LSd] = (T)ey_act(acc[t] + dwb[cc], p.dwact);
+    }
+    __syncthreads();
+    const long cur = tile, nxt = tile + gridDim.x;
+    if (nxt < p.ntile) issue_halo(nxt, hv);  // in flight during the pointwise phase
+    // ---- 3. pointwise GEMM: wave handles image rows wave and wave+8 of the tile (16 pixels each)
+    const int b = (int)(cur / tiles_img), trem = (int)(cur - (long)b * tiles_img);
+    const int ty0 = (trem / p.tilesX) * TH, tx0 = (trem % p.tilesX) * TW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = wave + 8 * h;
+      Vec8<T> bfr;
+      bfr.load(s_dw + row * ROWS + r * LSd + 8 * g);  // lanes with 8g >= C read pad / neighbour data against zero weight slack
+      f32x4 pacc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) pacc[nt] = ds_mma16(af[nt], bfr, (f32x4)0.f);
+      const int oy = ty0 + row, ox = tx0 + r;
+      if (oy >= p.H || ox >= p.W) continue;
+      const long m = ((long)b * p.H + oy) * p.W + ox;
+      float v[4 * NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = ey_act(pacc[nt][j] + bias[4 * nt + j], p.act);
+      T* yp = (T*)p.y + m * p.yCs + ch0;
+      const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
+#pragma unroll
+      for (int q = 0; q < NT; ++q) {
+        if (ch0 + 4 * q + 4 <= p.Cout) {
+          float o[4] = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+          if (rp) {
+            const f16x4 rr = *reinterpret_cast<const f16x4*>(rp + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += (float)rr[j];
+          }
+          const f16x4 ov = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]};
+          *reinterpret_cast<f16x4*>(yp + 4 * q) = ov;
+        }
+      }
+    }
+  }
+}
+
 // mirrors conv_igemm.hip (same packing rule)
 static int ds_conv_nt(int Cout) {
   if (Cout <= 16) return 1;
@@ -454,6 +589,75 @@ static int ds_strip_dispatch(const DsP& p, int k, hipStream_t st) {
   if (k == 3) return ds_strip_k<3>(p, nt, ks, st);
   if (k == 5) return ds_strip_k<5>(p, nt, ks, st);
   return ds_strip_k<7>(p, nt, ks, st);
+}
+
+// ---- Toeplitz fragments: out[((c*k + ky)*64 + lane)*8 + t] = w[ky][kx = 8g + t - i][c], lane = (i = lane & 15, g = lane >> 4)
+extern "C" size_t ey_dsconv_toeplitz_bytes(int C, int k) { return (size_t)C * k * 64 * 8 * sizeof(f16); }
+extern "C" int ey_dsconv_pack_toeplitz(int C, int k, const float* w_kkc_host, void* out_host, size_t out_bytes) {
+  EY_CHECK(C > 0 && (k == 3 || k == 5 || k == 7) && w_kkc_host && out_host, "pack_toeplitz: bad arguments");
+  EY_CHECK(out_bytes >= ey_dsconv_toeplitz_bytes(C, k), "pack_toeplitz: output buffer too small");
+  f16* o = (f16*)out_host;
+  for (int c = 0; c < C; ++c)
+    for (int ky = 0; ky < k; ++ky)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int t = 0; t < 8; ++t) {
+          const int i = lane & 15, g = lane >> 4, kx = 8 * g + t - i;
+          o[(((size_t)c * k + ky) * 64 + lane) * 8 + t] = (kx >= 0 && kx < k) ? (f16)w_kkc_host[((size_t)ky * k + kx) * C + c] : (f16)0.f;
+        }
+  return EY_OK;
+}
+
+template <int K, int NT, int CPW>
+static int ds_tz_launch(DsP p, const void* tz, hipStream_t st) {
+  constexpr int C = 8 * CPW, HH = 16 + K - 1, LSd = C + 8, ROWS = 16 * LSd + 8;
+  const size_t lds = ((size_t)C * HH * TZ_RS + 32 + 16 * ROWS + 64) * sizeof(f16);
+  p.tilesX = (p.W + 15) / 16; p.tilesY = (p.H + 15) / 16;
+  p.ntile = (long)p.B * p.tilesX * p.tilesY;
+  static int occ = 0;
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)dsconv_tz_kernel<K, NT, CPW>, 512, lds) != hipSuccess || n < 1) n = 1;
+    occ = n > 2 ? 2 : n;
+  }
+  long gx = 256L * occ;
+  if (gx > p.ntile) gx = p.ntile;
+  hipLaunchKernelGGL((dsconv_tz_kernel<K, NT, CPW>), dim3((unsigned)gx), dim3(512), lds, st, p, (const f16*)tz);
+  EY_LAUNCH_CHECK("ey_dsconv_tz");
+  return EY_OK;
+}
+
+extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,
+                         const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream);
+
+extern "C" int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,
+                            const void* w_dw_toeplitz, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride,
+                            const void* res, int res_cstride, ey_stream_t stream) {
+  const int es = 2;
+  // measured (tools/ds_bench.py): k = 7 always wins (85 -> 28 us at C16 160x160); k = 3/5 win once the map has >= 100k pixels
+  // (33 -> 24 us), below that the register-strip kernel's extra waves matter more.  EY_TZ_KMASK (decimal bit mask over k) overrides.
+  static const long tz_kmask = ds_env("EY_TZ_KMASK", 168), tz_minpx = ds_env("EY_TZ_MINPX", 100000);
+  const bool fits = dtype == EY_F16 && w_dw_toeplitz && (k == 3 || k == 5 || k == 7) && ((tz_kmask >> k) & 1) && (k == 7 || (long)B * H * W >= tz_minpx) &&
+                    (Cin == 16 || Cin == 32) && Cout <= 32 && Cout % 4 == 0 && x && y && w_pw_packed &&
+                    x_cstride >= Cin && (x_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(w_dw_toeplitz, 16) && (y_cstride * es) % 8 == 0 && ey_aligned(y, 8) &&
+                    (!res || ((res_cstride * es) % 8 == 0 && ey_aligned(res, 8))) && y_cstride >= Cout && (((long)B * H * W - 1) * x_cstride + Cin) * es < (1L << 31);
+  if (!fits)  // every other shape: the general entry point
+    return ey_dsconv(dtype, B, H, W, Cin, Cout, k, act, x, x_cstride, w_dw_kkc, dw_bias, dw_act, w_pw_packed, bias, y, y_cstride, res, res_cstride, stream);
+  DsP p;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
+  p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)((((long)B * H * W - 1) * x_cstride + Cin) * es);
+  p.wdw = w_dw_kkc; p.dwbias = dw_bias; p.dwact = dw_act; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
+  p.Kpad = ey_conv_kpad(Cin);
+  p.NTpack = ds_conv_nt(Cout);
+  p.vec_store = 1;
+  hipStream_t st = (hipStream_t)stream;
+#define TZ(KV)                                                                                                                             \
+  if (k == KV) {                                                                                                                       \
+    if (Cin == 16) return p.NTpack == 1 ? ds_tz_launch<KV, 1, 2>(p, w_dw_toeplitz, st) : ds_tz_launch<KV, 2, 2>(p, w_dw_toeplitz, st); \
+    return p.NTpack == 1 ? ds_tz_launch<KV, 1, 4>(p, w_dw_toeplitz, st) : ds_tz_launch<KV, 2, 4>(p, w_dw_toeplitz, st);               \
+  }
+  TZ(3) TZ(5) TZ(7)
+#undef TZ
+  return ey_set_error(EY_EINVAL, "dsconv_tz: k=%d", k);
 }
 
 extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride, const void* w_dw_kkc,

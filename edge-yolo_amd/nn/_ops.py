@@ -264,11 +264,19 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
     def build():
         wd, bd = dw_fn()
         wp, bp = pw_fn()
-        wk = wd.view(c, k, k).permute(1, 2, 0).contiguous().to(device=x.device, dtype=x.dtype)
+        wkf = wd.detach().float().view(c, k, k).permute(1, 2, 0).contiguous().cpu()  # [k][k][C] fp32 host
+        wk = wkf.to(device=x.device, dtype=x.dtype)
+        tz = None
+        if x.dtype == torch.float16 and c in (16, 32) and wp.shape[0] <= 32:  # Toeplitz-MFMA depthwise stage (ey_dsconv_tz)
+            nb = L.lib().ey_dsconv_toeplitz_bytes(c, k)
+            buf = torch.empty(nb, dtype=torch.uint8)
+            w16 = wkf.half().float().contiguous()  # the f16-rounded weights the other kernels use (kept alive across the call)
+            L.check(L.lib().ey_dsconv_pack_toeplitz(c, k, w16.data_ptr(), buf.data_ptr(), nb), "ey_dsconv_pack_toeplitz")
+            tz = buf.to(x.device)
         return (wk, (bd.to(x.device).float().contiguous() if bd is not None else None), pack_conv_weight(wp, x.dtype, x.device),
-                (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0])
+                (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0], tz)
 
-    wk, dwb, wp, bias, cout = mod._packed(_dev_key(x, "dsfused"), build)
+    wk, dwb, wp, bias, cout, tz = mod._packed(_dev_key(x, "dsfused"), build)
     if out is None:
         out = L.empty_nhwc(B, cout, H, W, x.dtype, x.device)
     elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, H, W):
@@ -277,10 +285,12 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
         res = L.as_nhwc(res)
     try:
       with _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}"):
-        L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
-                                  dwb.data_ptr() if dwb is not None else None, dw_act, wp.data_ptr(),
-                                  bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out),
-                                  res.data_ptr() if res is not None else None, L.cstride(res) if res is not None else 0, L.stream()), "ey_dsconv")
+        tail = (dwb.data_ptr() if dwb is not None else None, dw_act, wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out),
+                res.data_ptr() if res is not None else None, L.cstride(res) if res is not None else 0, L.stream())
+        if tz is not None:
+            L.check(L.lib().ey_dsconv_tz(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), tz.data_ptr(), *tail), "ey_dsconv_tz")
+        else:
+            L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), *tail), "ey_dsconv")
     except NotImplementedError:  # EY_EUNSUPPORTED is returned before anything is launched (tile does not fit LDS): two-kernel form
         return None
     return out

@@ -128,6 +128,16 @@ int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act,
               const void* w_dw_kkc, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias, void* y, int y_cstride, const void* res,
               int res_cstride, ey_stream_t stream);
 
+/* Toeplitz form of the depthwise stage for wide kernels (k = 7; f16; Cin 16 or 32, Cout <= 32): the row filter becomes one
+ * 16x16x32 MFMA per channel and filter row (7 MFMAs per channel per 16x16 tile instead of 12544 FMAs).  w_dw_toeplitz is
+ * built once on the host by ey_dsconv_pack_toeplitz from the fp32 [k][k][C] depthwise weights (ey_dsconv_toeplitz_bytes bytes,
+ * then uploaded).  Same arguments and result as ey_dsconv; shapes outside the Toeplitz kernel are forwarded to ey_dsconv. */
+size_t ey_dsconv_toeplitz_bytes(int C, int k);
+int ey_dsconv_pack_toeplitz(int C, int k, const float* w_dw_kkc_host, void* out_host, size_t out_bytes);
+int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, int k, int act, const void* x, int x_cstride,
+                 const void* w_dw_kkc, const void* w_dw_toeplitz, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias,
+                 void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream);
+
 /* ---- K4: single-level 2-D Haar analysis (_PywtDWT2D.forward, block.py:3619-3642).
  * x [B,H,W,C] -> y [B,H/2,W/2,4C] with channel blocks LL|LH|HL|HH; odd H/W floor like the stride-2 conv. */
 int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y, int y_cstride,
