@@ -781,19 +781,24 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
         issue_halo(c0 + CC, hv);
         issue_w(c0 + CC);
       }
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
+      // operand fragments double-buffered across taps: tap t+1's 8 LDS reads are issued before tap t's 16 MFMAs
+      Vec8<T> bfr[2][MT], afr[2][NT];
+      auto ld_tap = [&](int tap, Vec8<T> (&a)[NT], Vec8<T> (&bq)[MT]) {
         const int ky = tap / 3, kx = tap % 3;
         const int toff = ((S == 1) ? (ky * LROW + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
-        Vec8<T> bf[MT], a[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) a[nt].load(wlane + (tap * 16 * NT + nt * 16) * CP);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) bf[mt].load(hl + bbase[mt] + toff);
+        for (int mt = 0; mt < MT; ++mt) bq[mt].load(hl + bbase[mt] + toff);
+      };
+      ld_tap(0, afr[0], bfr[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) ld_tap(tap + 1, afr[(tap + 1) & 1], bfr[(tap + 1) & 1]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(a[nt], bf[mt], acc[mt][nt]);
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(afr[tap & 1][nt], bfr[tap & 1][mt], acc[mt][nt]);
       }
     }
   } else {

@@ -222,3 +222,20 @@ def test_dsconv_f16_kernel_agrees_with_exact_f32_kernel(M, c, k, h, w):
     got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
     scale = float(want.abs().max())
     torch.testing.assert_close(got, want, rtol=4e-3, atol=4e-3 * scale)
+
+
+@pytest.mark.parametrize("n_hw", [(20, 20), (13, 9), (40, 40), (7, 5)])
+def test_linear_attention_mfma_agrees_with_f32_kernel(n_hw):
+    """f16 mode runs the MFMA linear-attention kernel (head_dim 64), f32 mode the fp32 VALU kernel: same f16-representable qkv ->
+    they differ by the f16 rounding of softmax(k), ctx and softmax(q) (the reference's half-precision matmul operands) only."""
+    from edge_yolo_amd.nn import _ops
+    from edge_yolo_amd import _lib as L
+    h, w = n_hw
+    torch.manual_seed(h * 100 + w)
+    qkv = L.empty_nhwc(3, 384, h, w, torch.float16, "cuda")
+    qkv.copy_((torch.randn(3, 384, h, w) * 1.5).half())
+    got = _ops.linear_attention(qkv, 2).float().cpu()
+    q32 = L.empty_nhwc(3, 384, h, w, torch.float32, "cuda")
+    q32.copy_(qkv.float())
+    want = _ops.linear_attention(q32, 2).float().cpu()
+    torch.testing.assert_close(got, want, rtol=1e-2, atol=2e-3 * float(want.abs().max()))
