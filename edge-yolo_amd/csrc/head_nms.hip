@@ -8,12 +8,35 @@
 // to an odd number of 16-byte units, so the per-anchor row reads that follow are bank-conflict free); a thread then
 // decodes one anchor entirely from LDS and writes its 4+nc outputs, coalesced across threads, to pred (B,4+nc,A).
 #define HD_ANCH 128
+#define HD_MAXL 4
+// Up to HD_MAXL pyramid levels in ONE launch: the 20x20 and 40x40 levels are a few hundred short-lived workgroups each, far too
+// few to fill the chip on their own; behind the 80x80 level's 1600 workgroups they cost nothing.  blk0[l] = first block of level l.
+struct HdLevels {
+  int nl;
+  int H[HD_MAXL], W[HD_MAXL], boxCs[HD_MAXL], clsCs[HD_MAXL], a_off[HD_MAXL], blk0[HD_MAXL + 1];
+  float stride[HD_MAXL];
+  const void* box[HD_MAXL];
+  const void* cls[HD_MAXL];
+  const float* w1[HD_MAXL];
+  const float* b1[HD_MAXL];
+  const float* w2[HD_MAXL];
+  const float* b2[HD_MAXL];
+};
 template <typename T>
-__global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int W, int nc, float stride, const T* __restrict__ box, int boxCs,
-                                                              const T* __restrict__ cls, int clsCs, const float* __restrict__ w1,
-                                                              const float* __restrict__ b1, const float* __restrict__ w2,
-                                                              const float* __restrict__ b2, int hid, float* __restrict__ pred, int A, int a_off,
-                                                              int boxLs, int clsLs, int vec) {
+__global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv, int nc, int hid, float* __restrict__ pred, int A, int boxLs, int clsLs, int vec) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < HD_MAXL; ++i)
+    if (i < lv.nl && (int)blockIdx.x >= lv.blk0[i]) l = i;
+  const int H = lv.H[l], W = lv.W[l], boxCs = lv.boxCs[l], clsCs = lv.clsCs[l], a_off = lv.a_off[l];
+  const float stride = lv.stride[l];
+  const T* __restrict__ box = (const T*)lv.box[l];
+  const T* __restrict__ cls = (const T*)lv.cls[l];
+  const float* __restrict__ w1 = lv.w1[l];
+  const float* __restrict__ b1 = lv.b1[l];
+  const float* __restrict__ w2 = lv.w2[l];
+  const float* __restrict__ b2 = lv.b2[l];
+  const int blk = (int)blockIdx.x - lv.blk0[l];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* s_box = reinterpret_cast<T*>(smem);           // [HD_ANCH][boxLs]  (scalar path only: boxLs == 0 on the vector path)
   T* s_cls = s_box + HD_ANCH * boxLs;              // [HD_ANCH][clsLs]
@@ -22,7 +45,7 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, int H, int 
   float* s_w2 = s_b1 + hid;
   const int HW = H * W;
   const long total = (long)B * HW;
-  const long idx0 = (long)blockIdx.x * HD_ANCH;
+  const long idx0 = (long)blk * HD_ANCH;
   const int tid = threadIdx.x;
   const int nrow = (int)min((long)HD_ANCH, total - idx0);
   if (vec) {
@@ -126,36 +149,58 @@ static int hd_pad(int elems, int es) {  // row stride (elements): 16-byte aligne
   return units * 16 / es;
 }
 
-extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const void* box, int box_cstride, const void* cls,
-                              int cls_cstride, const float* q_w1, const float* q_b1, const float* q_w2, const float* q_b2, int q_hidden,
-                              float* pred, int A_total, int a_off, ey_stream_t stream) {
-  EY_CHECK(box && cls && pred, "head_decode: null pointer");
+extern "C" int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
+                                     const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
+                                     const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, ey_stream_t stream) {
+  EY_CHECK(pred && H && W && stride && box && cls && box_cstride && cls_cstride && a_off, "head_decode: null pointer");
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "head_decode: bad dtype");
-  EY_CHECK(B > 0 && H > 0 && W > 0 && nc > 0, "head_decode: bad extent");
-  EY_CHECK(box_cstride >= 64 && cls_cstride >= nc, "head_decode: cstride");
-  EY_CHECK(a_off >= 0 && a_off + H * W <= A_total, "head_decode: level [%d,%d) outside A=%d", a_off, a_off + H * W, A_total);
-  EY_CHECK(!q_w1 || (q_b1 && q_w2 && q_b2 && q_hidden > 0), "head_decode: incomplete quality head");
+  EY_CHECK(nlevels >= 1 && nlevels <= HD_MAXL, "head_decode: %d levels (1..%d)", nlevels, HD_MAXL);
+  EY_CHECK(B > 0 && nc > 0, "head_decode: bad extent");
   const int es = dtype == EY_F16 ? 2 : 4;
-  const int vec = nc % 8 == 0 && (box_cstride * es) % 16 == 0 && (cls_cstride * es) % 16 == 0 && ey_aligned(box, 16) && ey_aligned(cls, 16);
+  const bool quality = q_w1 && q_w1[0];
+  HdLevels lv;
+  lv.nl = nlevels;
+  int vec = nc % 8 == 0;
+  long nblk = 0;
+  for (int l = 0; l < HD_MAXL; ++l) {
+    const int s = l < nlevels ? l : 0;
+    EY_CHECK(box[s] && cls[s] && H[s] > 0 && W[s] > 0, "head_decode: level %d: bad extent / null pointer", s);
+    EY_CHECK(box_cstride[s] >= 64 && cls_cstride[s] >= nc, "head_decode: cstride");
+    EY_CHECK(a_off[s] >= 0 && a_off[s] + H[s] * W[s] <= A_total, "head_decode: level [%d,%d) outside A=%d", a_off[s], a_off[s] + H[s] * W[s], A_total);
+    EY_CHECK(!quality || (q_w1[s] && q_b1 && q_b1[s] && q_w2 && q_w2[s] && q_b2 && q_b2[s] && q_hidden > 0), "head_decode: incomplete quality head");
+    lv.H[l] = H[s]; lv.W[l] = W[s]; lv.stride[l] = stride[s]; lv.box[l] = box[s]; lv.cls[l] = cls[s]; lv.boxCs[l] = box_cstride[s]; lv.clsCs[l] = cls_cstride[s];
+    lv.a_off[l] = a_off[s];
+    lv.w1[l] = quality ? q_w1[s] : nullptr; lv.b1[l] = quality ? q_b1[s] : nullptr; lv.w2[l] = quality ? q_w2[s] : nullptr; lv.b2[l] = quality ? q_b2[s] : nullptr;
+    vec = vec && (box_cstride[s] * es) % 16 == 0 && (cls_cstride[s] * es) % 16 == 0 && ey_aligned(box[s], 16) && ey_aligned(cls[s], 16);
+    lv.blk0[l] = (int)nblk;
+    if (l < nlevels) nblk += ((long)B * H[s] * W[s] + HD_ANCH - 1) / HD_ANCH;
+  }
+  lv.blk0[HD_MAXL] = (int)nblk;
+  EY_CHECK(nblk < (1L << 31), "head_decode: too many anchors");
   const int boxLs = vec ? 0 : hd_pad(64, es), clsLs = hd_pad(nc, es);
-  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es + (q_w1 ? (size_t)q_hidden * 22 * 4 : 0);
+  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es + (quality ? (size_t)q_hidden * 22 * 4 : 0);
   EY_CHECK(lds <= 160 * 1024, "head_decode: nc=%d needs %zu B of LDS", nc, lds);
-  const long total = (long)B * H * W;
-  dim3 grid((unsigned)((total + HD_ANCH - 1) / HD_ANCH));
+  dim3 grid((unsigned)nblk);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EY_F16) {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(HD_ANCH), lds, st, B, H, W, nc, stride, (const f16*)box, box_cstride, (const f16*)cls,
-                       cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, boxLs, clsLs, vec);
+    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec);
   } else {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(HD_ANCH), lds, st, B, H, W, nc, stride, (const float*)box, box_cstride,
-                       (const float*)cls, cls_cstride, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, boxLs, clsLs, vec);
+    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec);
   }
   EY_LAUNCH_CHECK("ey_head_decode");
   return EY_OK;
+}
+
+extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const void* box, int box_cstride, const void* cls,
+                              int cls_cstride, const float* q_w1, const float* q_b1, const float* q_w2, const float* q_b2, int q_hidden,
+                              float* pred, int A_total, int a_off, ey_stream_t stream) {
+  EY_CHECK(box && cls && pred, "head_decode: null pointer");
+  EY_CHECK(!q_w1 || (q_b1 && q_w2 && q_b2 && q_hidden > 0), "head_decode: incomplete quality head");
+  return ey_head_decode_levels(dtype, B, 1, &H, &W, &stride, &box, &box_cstride, &cls, &cls_cstride, nc, &q_w1, &q_b1, &q_w2, &q_b2, q_hidden, pred, A_total, &a_off, stream);
 }
 
 // ============================================================================ NMS

@@ -396,6 +396,28 @@ def head_decode(box, cls, stride, q, pred, a_off):
                                        qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
 
 
+def head_decode_levels(levels, pred):
+    """levels: list (<= 4) of (box, cls, stride, q-or-None, a_off) -> every level of the fused DGQP + DFL + decode in ONE launch."""
+    n = len(levels)
+    box0, cls0 = levels[0][0], levels[0][1]
+    L.require_device(box0, "head_decode")
+    B, nc = box0.shape[0], cls0.shape[1]
+    q0 = levels[0][3]
+    hid = q0[0].shape[0] if q0 is not None else 0
+    IA, FA, PA = ctypes.c_int * n, ctypes.c_float * n, ctypes.c_void_p * n
+    Hs, Ws = IA(*[lv[0].shape[2] for lv in levels]), IA(*[lv[0].shape[3] for lv in levels])
+    st = FA(*[float(lv[2]) for lv in levels])
+    boxp, clsp = PA(*[lv[0].data_ptr() for lv in levels]), PA(*[lv[1].data_ptr() for lv in levels])
+    boxcs, clscs = IA(*[L.cstride(lv[0]) for lv in levels]), IA(*[L.cstride(lv[1]) for lv in levels])
+    offs = IA(*[int(lv[4]) for lv in levels])
+    qa = [PA(*[(lv[3][j].data_ptr() if lv[3] is not None else None) for lv in levels]) for j in range(4)]
+    nbytes = sum(_nb(lv[0], lv[1]) + B * lv[0].shape[2] * lv[0].shape[3] * (4 + nc) * 4 for lv in levels)
+    flops = sum(2.0 * B * lv[0].shape[2] * lv[0].shape[3] * (hid * 21 + 200) for lv in levels)
+    with _tr("head_decode_kernel", nbytes, flops, note=f"{n} levels"):
+        L.check(L.lib().ey_head_decode_levels(L.dtype_code(box0.dtype), B, n, Hs, Ws, st, boxp, boxcs, clsp, clscs, nc, qa[0], qa[1], qa[2], qa[3], hid,
+                                              pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")
+
+
 def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None, multi_label=False):
     """pred fp32 (B,4+nc,A) contiguous -> (boxes (B,max_det,6) fp32, count (B,) int32, index (B,max_det) int32)."""
     L.require_device(pred, "nms")

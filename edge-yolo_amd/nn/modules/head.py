@@ -115,13 +115,20 @@ class Detect(nn.Module):
         a_off = 0
         if getattr(self, "_stride_f", None) is None:
             self._stride_f = [float(s) for s in self.stride]  # host copy once (no D2H inside a captured graph)
+        levels = []
         for i, t in enumerate(xs):
             H, W = t.shape[2:]
             raw = L.empty_nhwc(B, (self.no + 7) // 8 * 8, H, W, dt, dev)[:, :self.no]  # pixel stride kept 16-byte aligned for any nc
             self._towers(i, t, raw)
-            ops.head_decode(raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), pred, a_off)
+            levels.append((raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), a_off))
             a_off += H * W
             x[i] = raw
+        # every level is decoded by ONE launch (reference: Detect._inference runs after all towers, head.py:84-90,117-148)
+        if len(levels) <= 4:
+            ops.head_decode_levels(levels, pred)
+        else:
+            for box, cls, st, q, off in levels:
+                ops.head_decode(box, cls, st, q, pred, off)
         return pred if self.export else (pred, x)
 
     def bias_init(self):

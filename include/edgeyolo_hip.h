@@ -184,6 +184,14 @@ int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const v
                    const void* cls, int cls_cstride, const float* q_w1, const float* q_b1, const float* q_w2,
                    const float* q_b2, int q_hidden, float* pred, int A_total, int a_off, ey_stream_t stream);
 
+/* All pyramid levels of one head in ONE launch (arrays of length nlevels <= 4; same nc / q_hidden for every level; q_* arrays
+ * NULL or holding NULLs for plain Detect).  Same arithmetic as ey_head_decode per level: Detect.forward decodes every level
+ * after all towers ran (head.py:84-90,117-148), so the three small launches collapse into one grid that fills the chip. */
+int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box,
+                          const int* box_cstride, const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1,
+                          const float* const* q_b1, const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred,
+                          int A_total, const int* a_off, ey_stream_t stream);
+
 /* ---- K11: batched per-image NMS (non_max_suppression, utils/ops.py:230-316, and the torchvision.ops.nms it calls
  * at :296).  multi_label=0: best class per anchor (predict, ops.py:273-275); multi_label=1: one candidate per
  * (anchor, class) pair above conf (validation, ops.py:270-272; needs the _ml workspace).
