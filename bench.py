@@ -112,7 +112,8 @@ def main():
         boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
         return boxes, count
 
-    gather = eydist.BoxGatherer(world, a.batch, max_det, dev) if (world > 1 or force_gather) else None
+    # pipelined mode: the gather rides on the post-processing stream (no stream of its own)
+    gather = eydist.BoxGatherer(world, a.batch, max_det, dev, own_stream=a.no_pipeline) if (world > 1 or force_gather) else None
     if a.no_pipeline:
         runner = GraphRunner(device_step)
         images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy

@@ -39,7 +39,9 @@ class BoxGatherer:
     """Double-buffered all_gather of packed result rows.  On CUDA/ROCm it runs on its own stream: the producer stream
     only waits for the staging copy of the previous call, so the collective overlaps the next batch."""
 
-    def __init__(self, world, batch_local, max_det, device, group=None):
+    def __init__(self, world, batch_local, max_det, device, group=None, own_stream=True):
+        """own_stream=False: pack + collective are enqueued on the caller's current stream (for callers that already run the
+        post-processing on a stream of its own: every extra active stream costs hardware-queue sharing with the forward graph)."""
         self.world, self.B, self.max_det, self.group = world, batch_local, max_det, group
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
@@ -47,14 +49,20 @@ class BoxGatherer:
         self.stage = [torch.zeros((batch_local, w), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.gathered = [torch.zeros((world * batch_local, w), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.i = 0
-        self.side = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and own_stream) else None
         self.copied = [None, None]
         self.done = [None, None]
 
     def __call__(self, boxes, count):
         j = self.i & 1
         self.i += 1
-        if self.cuda:
+        if self.cuda and self.side is None:
+            pack_rows(boxes, count, self.stage[j])
+            dist.all_gather_into_tensor(self.gathered[j], self.stage[j], group=self.group)
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.done[j] = done
+        elif self.cuda:
             main = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(main)
@@ -75,8 +83,12 @@ class BoxGatherer:
         return self.gathered[j]
 
     def wait(self):
-        if self.cuda:
+        if self.cuda and self.side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
+        elif self.cuda:
+            for d in self.done:
+                if d is not None:
+                    torch.cuda.current_stream(self.device).wait_event(d)
 
     def results(self, j=None):
         j = (self.i - 1) & 1 if j is None else j

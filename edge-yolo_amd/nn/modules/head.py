@@ -5,6 +5,7 @@ score modulation) is ONE fused kernel per pyramid level writing the (B, 4+nc, A)
 """
 import copy
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -16,6 +17,10 @@ from ... import _lib as L
 
 __all__ = ("Detect", "GF2Detect", "GFLHeadv2_uniH")
 
+
+_HEAD_STREAMS = os.environ.get("EY_HEAD_STREAMS", "1") != "0"
+# developer override: stream index (0 = the caller's stream) of each tower in order (level0 box, level0 cls, level1 box, ...)
+_HEAD_MAP = [int(v) for v in os.environ["EY_HEAD_MAP"].split(",")] if os.environ.get("EY_HEAD_MAP") else None
 
 class _Plain(_Packed):
     """Weights of a bare nn.Conv2d(+bias) 1x1 tower tail, packed for the MFMA conv."""
@@ -74,15 +79,22 @@ class Detect(nn.Module):
         self._stride_f = None
         return super()._apply(fn, *a, **k)
 
-    def _towers(self, i, x, raw):
-        """box logits -> raw[:, :64], class logits -> raw[:, 64:]."""
+    def _box_tower(self, i, x, raw):
+        """box logits -> raw[:, :64]."""
         b = self.cv2[i]
         self._tail(b[2]).run(b[1](b[0](x)), raw[:, :4 * self.reg_max])
+
+    def _cls_tower(self, i, x, raw):
+        """class logits -> raw[:, 64:]."""
         c = self.cv3[i]
         t = x
         for j in range(len(c) - 1):
             t = c[j](t)  # (self._dw_pw fuses DWConv+Conv into one kernel; measured slower than the two kernels at these widths)
         self._tail(c[-1]).run(t, raw[:, 4 * self.reg_max:])
+
+    def _towers(self, i, x, raw):
+        self._box_tower(i, x, raw)
+        self._cls_tower(i, x, raw)
 
     @staticmethod
     def _dw_pw(blk, t):
@@ -116,13 +128,36 @@ class Detect(nn.Module):
         if getattr(self, "_stride_f", None) is None:
             self._stride_f = [float(s) for s in self.stride]  # host copy once (no D2H inside a captured graph)
         levels = []
+        # The towers of the pyramid levels are independent: the small levels run on a second HIP stream (fork / join around them),
+        # which a captured hipGraph records as a parallel branch -- the 20x20 and 40x40 towers (a few hundred workgroups per kernel)
+        # then run beside the 80x80 ones instead of after them (2.18 -> 2.08 ms/step).  More branches are slower (3 level streams
+        # 2.38 ms, 6 tower streams 2.40 ms: the persistent kernels fight for the CUs).  EY_HEAD_STREAMS=0 keeps one stream.
+        fork = _HEAD_STREAMS and dev.type == "cuda" and len(xs) > 1
+        cur = torch.cuda.current_stream(dev) if fork else None
+        # default: the first (largest) level on the caller's stream, all smaller levels one after the other on ONE side stream
+        smap = _HEAD_MAP if (_HEAD_MAP and len(_HEAD_MAP) == 2 * len(xs)) else [0, 0] + [1] * (2 * len(xs) - 2)
+        if fork and (getattr(self, "_side", None) is None or self._side_dev != dev or len(self._side) != max(smap)):
+            self._side, self._side_dev = [torch.cuda.Stream(device=dev) for _ in range(max(smap))], dev
+        if fork:
+            for side in self._side:
+                side.wait_stream(cur)
+        task = 0
         for i, t in enumerate(xs):
             H, W = t.shape[2:]
             raw = L.empty_nhwc(B, (self.no + 7) // 8 * 8, H, W, dt, dev)[:, :self.no]  # pixel stride kept 16-byte aligned for any nc
-            self._towers(i, t, raw)
+            for tower in (self._box_tower, self._cls_tower):
+                if fork and smap[task] > 0:
+                    with torch.cuda.stream(self._side[smap[task] - 1]):
+                        tower(i, t, raw)
+                else:
+                    tower(i, t, raw)
+                task += 1
             levels.append((raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), a_off))
             a_off += H * W
             x[i] = raw
+        if fork:
+            for side in self._side:
+                cur.wait_stream(side)
         # every level is decoded by ONE launch (reference: Detect._inference runs after all towers, head.py:84-90,117-148)
         if len(levels) <= 4:
             ops.head_decode_levels(levels, pred)
