@@ -40,6 +40,7 @@ struct ConvP {
   long ntile;    // number of wave tiles (16*MT pixels each)
   int ntn;       // number of channel tiles (small-M kernel)
   int vec_store; // 1: y/res/addz views are aligned for 4-element vector access
+  int tTR, tTC;  // stride-1 3x3 tile kernel: output tile rows x columns (tTR*tTC <= 256 pixels, (tTR+2)*(tTC+2) <= 340 halo pixels)
 };
 
 __device__ __forceinline__ f32x4 mma16(const Vec8<f16>& a, const Vec8<f16>& b, f32x4 c) {
@@ -706,9 +707,14 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
   T* wl = hl + HR * LROW * CP;                             // [9][16*NT][CP]   (WLDS)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
   const int grp = blockIdx.z, n_base = blockIdx.y * (16 * NT);
-  const int tilesX = (p.Wo + TC - 1) / TC, tilesY = (p.Ho + TR - 1) / TR, tiles_img = tilesX * tilesY;
+  // stride 1: the tile is tTR x tTC output pixels FLATTENED onto the 256 pixel slots (slot q = row*tTC + col), chosen on the host so
+  // that small maps are covered with little waste (20x20 -> 12x20 tiles: 78 % of the slots do useful work instead of 52 % with 8x32);
+  // stride 2: the fixed 8 x 16 tile with the parity-split halo.
+  const int tTR = (S == 1) ? p.tTR : TR, tTC = (S == 1) ? p.tTC : TC;
+  const int hHR = (S == 1) ? tTR + 2 : HR, hHC = (S == 1) ? tTC + 2 : HC, lrow = (S == 1) ? hHC : LROW;
+  const int tilesX = (p.Wo + tTC - 1) / tTC, tilesY = (p.Ho + tTR - 1) / tTR, tiles_img = tilesX * tilesY;
   const int b = blockIdx.x / tiles_img, trem = blockIdx.x - b * tiles_img;
-  const int oy0 = (trem / tilesX) * TR, ox0 = (trem % tilesX) * TC;
+  const int oy0 = (trem / tilesX) * tTR, ox0 = (trem % tilesX) * tTC;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int Cin = p.srcC[0];
   const __amdgpu_buffer_rsrc_t rs = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
@@ -723,12 +729,12 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
 #pragma unroll
   for (int u = 0; u < NHV; ++u) {
     const int v = threadIdx.x + u * 256;
-    const int px = v >> 2, cv = v & 3, hy = px / HC, hx = px - hy * HC;
+    const int px = v >> 2, cv = v & 3, hy = px / hHC, hx = px - hy * hHC;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool ok = v < HR * HC * 4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    const bool ok = v < hHR * hHC * 4 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     hgo[u] = ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.srcCs[0] + cv * 8) * (int)sizeof(T)) : EY_OOB;
-    const int lpix = (S == 1) ? hy * LROW + hx : hy * LROW + (hx & 1) * HCH + (hx >> 1);
-    hlo[u] = v < HR * HC * 4 ? lpix * CP + cv * 8 : -1;
+    const int lpix = (S == 1) ? hy * lrow + hx : hy * LROW + (hx & 1) * HCH + (hx >> 1);
+    hlo[u] = v < hHR * hHC * 4 ? lpix * CP + cv * 8 : -1;
     hcv[u] = cv * 8;
   }
   auto issue_halo = [&](int c0, Vec8<T> (&hv)[NHV]) {
@@ -736,11 +742,21 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
     for (int u = 0; u < NHV; ++u) BufLoad8<T>::load(hv[u], rs, (c0 + hcv[u]) < Cin ? hgo[u] : EY_OOB, c0 * (int)sizeof(T));
   };
   // fragment base of this lane in the halo: wave owns output rows 2*wave, 2*wave+1; block mt = (row mt/MTC, column block mt%MTC)
-  int bbase[MT];
+  int bbase[MT], prow[MT], pcol[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int row = 2 * wave + mt / MTC, col = (mt % MTC) * 16 + r;
-    bbase[mt] = ((S == 1) ? (row * LROW + col) : (row * 2 * LROW + col)) * CP + 8 * g;
+    if constexpr (S == 1) {
+      const int q = wave * 64 + mt * 16 + r;  // pixel slot
+      const bool qv = q < tTR * tTC;
+      prow[mt] = qv ? q / tTC : 0;
+      pcol[mt] = qv ? q - prow[mt] * tTC : 0;
+      bbase[mt] = (prow[mt] * lrow + pcol[mt]) * CP + 8 * g;
+      if (!qv) prow[mt] = 1 << 20;  // never stored
+    } else {
+      prow[mt] = 2 * wave + mt / MTC;
+      pcol[mt] = (mt % MTC) * 16 + r;
+      bbase[mt] = (prow[mt] * 2 * LROW + pcol[mt]) * CP + 8 * g;
+    }
   }
 
   f32x4 acc[MT][NT];
@@ -785,7 +801,7 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
       Vec8<T> bfr[2][MT], afr[2][NT];
       auto ld_tap = [&](int tap, Vec8<T> (&a)[NT], Vec8<T> (&bq)[MT]) {
         const int ky = tap / 3, kx = tap % 3;
-        const int toff = ((S == 1) ? (ky * LROW + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
+        const int toff = ((S == 1) ? (ky * lrow + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) a[nt].load(wlane + (tap * 16 * NT + nt * 16) * CP);
 #pragma unroll
@@ -825,7 +841,7 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
       const int ky = tap / 3, kx = tap % 3;
       if (tap + 3 < 9) load_w(tap + 3, c0, af[(tap + 3) & 3]);
       else if (more) load_w(tap + 3 - 9, c0 + CC, af[(tap + 3) & 3]);
-      const int toff = ((S == 1) ? (ky * LROW + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
+      const int toff = ((S == 1) ? (ky * lrow + kx) : (ky * LROW + (kx & 1) * HCH + (kx >> 1))) * CP;
       Vec8<T> bf[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) bf[mt].load(hl + bbase[mt] + toff);
@@ -845,7 +861,7 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
   const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int oy = oy0 + 2 * wave + mt / MTC, ox = ox0 + (mt % MTC) * 16 + r;
+    const int oy = oy0 + prow[mt], ox = ox0 + pcol[mt];
     if (oy < p.Ho && ox < p.Wo) conv_epilogue<T, NT>(p, acc[mt], ((long)b * p.Ho + oy) * p.Wo + ox, b, oy, ox, ch0, grp);
   }
 }
@@ -1168,6 +1184,8 @@ struct EyTune {
   long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
   long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 128); // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
+  long tile_minwg = ey_env("EY_TILE_MINWG", 400);     // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
+  long tile_flat = ey_env("EY_TILE_FLAT", 1);         // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)
   long tile_mink = ey_env("EY_TILE_MINK", 0);         // 3x3 tile kernel for K = 9*Cin >= this (huge value = off)
   long pwr_m = ey_env("EY_PWR_M", 110000);            // register-stationary pointwise kernel from this many output pixels (huge value = off)
   long pwr_frags = ey_env("EY_PWR_FRAGS", 24);        // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
@@ -1329,7 +1347,23 @@ static int tile_launch(ConvP p, int ngroup, hipStream_t st) {
   constexpr int TR = 8, TC = (S == 1) ? 32 : 16, HR = (TR - 1) * S + 3, HC = (TC - 1) * S + 3, LROW = (S == 1) ? HC : 2 * ((HC + 1) / 2);
   const bool wlds = tune().tile_wlds == 1 || (tune().tile_wlds == 2 && S == 1);
   const size_t lds = ((size_t)HR * LROW + (wlds ? 9 * 16 * NT : 0)) * 40 * sizeof(T);
-  const long tiles = (long)p.B * ((p.Wo + TC - 1) / TC) * ((p.Ho + TR - 1) / TR);
+  int tr = TR, tc = TC;
+  if (S == 1 && tune().tile_flat) {  // flattened tile: the (rows x cols) with <= 256 pixels and <= 340 halo pixels that wastes the fewest slots
+    double best = 0.0;
+    const int cands[8] = {16, 20, 24, 28, 32, 36, 40, p.Wo};
+    for (int i = 0; i < 8; ++i) {
+      const int c = cands[i];
+      if (c < 8 || c > 80) continue;
+      int rr = 256 / c;
+      while (rr > 1 && (rr + 2) * (c + 2) > 340) --rr;
+      if (rr < 1 || (rr + 2) * (c + 2) > 340) continue;
+      const long cov = (long)((p.Wo + c - 1) / c) * ((p.Ho + rr - 1) / rr) * 256;
+      const double eff = (double)p.Wo * p.Ho / (double)cov;
+      if (eff > best + 1e-9) { best = eff; tr = rr; tc = c; }
+    }
+  }
+  p.tTR = tr; p.tTC = tc;
+  const long tiles = (long)p.B * ((p.Wo + tc - 1) / tc) * ((p.Ho + tr - 1) / tr);
   const dim3 grid((unsigned)tiles, (unsigned)(conv_cout_pad(p.Cout) / (16 * NT)), (unsigned)ngroup);
   static bool attr = false;
   if (!attr) {  // up to 46 + 46 KB of dynamic LDS
@@ -1350,8 +1384,13 @@ static int dispatch_tile(ConvP p, int ngroup, hipStream_t st) {
   if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || 9L * p.srcC[0] < tune().tile_mink) return 0;
   if (p.stride == 2 && (p.srcC[0] < tune().tile_s2_minc || (long)p.B * p.Ho * p.Wo < tune().tile_s2_minm)) return 0;
   const int ntp = conv_nt(p.Cout);
-  const int nt = ntp % 4 == 0 ? 4 : ntp == 2 ? 2 : ntp == 1 ? 1 : 0;
+  int nt = ntp % 4 == 0 ? 4 : ntp == 2 ? 2 : ntp == 1 ? 1 : 0;
   if (!nt) return 0;
+  // small maps: too few tiles to fill 256 CUs -> narrower channel tiles (more workgroups) beat the bigger register tile
+  if (p.stride == 1 && tune().tile_minwg > 0) {
+    const long tiles = (long)p.B * (((long)p.Ho * p.Wo + 239) / 240);
+    while (nt > 1 && tiles * (conv_cout_pad(p.Cout) / (16 * nt)) * ngroup < tune().tile_minwg) nt >>= 1;
+  }
   const long npix = (long)p.B * p.H * p.W;
   const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * (long)sizeof(T);
   if (bytes >= (1L << 31) || p.srcG * (long)sizeof(T) * (ngroup - 1) >= (1L << 31)) return 0;

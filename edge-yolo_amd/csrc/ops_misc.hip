@@ -1,6 +1,7 @@
 // HBM-bound NHWC operators of the EdgeLine-YOLO forward path: stem conv, depthwise conv, Haar DWT, SPPF pooling,
 // slice copies / layout transposes, and the generic scalar direct convolution (correctness path for odd shapes).
 #include "common.h"
+#include <stdlib.h>
 
 // ============================================================================ generic direct conv (scalar)
 template <typename T>
@@ -132,6 +133,86 @@ __global__ __launch_bounds__(256) void stem_kernel(int B, int H, int W, int Ho, 
   }
 }
 
+// MFMA stem (f16 image -> f16 NHWC, Cin = 3, W % 8 == 0): the direct kernel above spends 27 x Cout FMAs per pixel on the
+// vector units (864 per thread) and is VALU-bound at 2.4 TB/s.  As a GEMM the layer is K = 27 (padded to 32), N = Cout: ONE
+// 16x16x32 MFMA per 16 pixels per 16 channels.  A workgroup stages the 3 x 17 x 144 input patch of an 8 x 64 output tile into LDS
+// with aligned 16-byte loads of the planar image (range-checked: zero padding), then every lane gathers its 8 taps
+// (k = c*9 + ky*3 + kx, the OIHW order) with 2-byte LDS reads; weights are converted once per wave into the A fragment.
+#define STM_TR 8
+#define STM_TC 64
+#define STM_LW 152  // LDS row stride (elements): 144 loaded columns + 8
+template <int NT>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(int B, int H, int W, int Ho, int Wo, int act, const f16* __restrict__ x, unsigned xbytes,
+                                                        const float* __restrict__ w, const float* __restrict__ bias, f16* __restrict__ y, int yCs) {
+  constexpr int HR = 2 * STM_TR + 1, NV = 3 * HR * 18;
+  __shared__ __attribute__((aligned(16))) f16 s_in[3 * HR * STM_LW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int tilesX = (Wo + STM_TC - 1) / STM_TC, tilesY = (Ho + STM_TR - 1) / STM_TR;
+  const int b = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - b * (tilesX * tilesY);
+  const int oy0 = (trem / tilesX) * STM_TR, ox0 = (trem % tilesX) * STM_TC;
+  const int iy0 = 2 * oy0 - 1, ixa = 2 * ox0 - 8;  // first staged input row / (8-aligned) column
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc(x, xbytes);
+#pragma unroll
+  for (int u = 0; u < (NV + 255) / 256; ++u) {
+    const int v = tid + u * 256;
+    if (v < NV) {
+      const int c = v / (HR * 18), rem = v - c * (HR * 18), row = rem / 18, vc = rem - row * 18;
+      const int iy = iy0 + row, ix = ixa + 8 * vc;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;  // W % 8 == 0: a vector is entirely inside or entirely outside
+      Vec8<f16> t;
+      BufLoad8<f16>::load(t, rs, ok ? (unsigned)(((((long)b * 3 + c) * H + iy) * W + ix) * 2) : EY_OOB);
+      t.store(s_in + (c * HR + row) * STM_LW + 8 * vc);
+    }
+  }
+  // A fragments (weights, fp32 OIHW -> f16) and this lane's tap offsets: k = 8g + t = c*9 + ky*3 + kx
+  Vec8<f16> af[NT];
+  int off[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int k = 8 * g + t, c = k / 9, ky = (k - 9 * c) / 3, kx = k - 9 * c - 3 * ky;
+    off[t] = k < 27 ? (c * HR + ky) * STM_LW + kx : 0;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) af[nt].v[t] = k < 27 ? (f16)w[(nt * 16 + r) * 27 + k] : (f16)0.f;
+  }
+  float bs[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bs[nt][j] = bias ? bias[nt * 16 + 4 * g + j] : 0.f;
+  __syncthreads();
+  // wave w: output rows 2w, 2w+1 of the tile, 4 column blocks of 16 pixels each
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk) {
+    const int rr = 2 * wave + (blk >> 2), j = (blk & 3) * 16 + r;
+    const f16* bp = s_in + (2 * rr) * STM_LW + 2 * j + 7;
+    Vec8<f16> bq;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) bq.v[t] = bp[off[t]];
+    const int oy = oy0 + rr, ox = ox0 + j;
+    const bool ok = oy < Ho && ox < Wo;
+    f16* yp = y + (((long)b * Ho + oy) * Wo + ox) * yCs + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt].v, bq.v, (f32x4)0.f, 0, 0, 0);
+      if (ok) {
+        const f16x4 o = {(f16)ey_act(acc[0] + bs[nt][0], act), (f16)ey_act(acc[1] + bs[nt][1], act), (f16)ey_act(acc[2] + bs[nt][2], act),
+                         (f16)ey_act(acc[3] + bs[nt][3], act)};
+        *reinterpret_cast<f16x4*>(yp + nt * 16) = o;
+      }
+    }
+  }
+}
+
+template <int NT>
+static int stem_mfma_launch(int B, int H, int W, int act, const void* x, const float* w, const float* bias, void* y, int yCs, hipStream_t st) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long tiles = (long)B * ((Wo + STM_TC - 1) / STM_TC) * ((Ho + STM_TR - 1) / STM_TR);
+  hipLaunchKernelGGL((stem_mfma_kernel<NT>), dim3((unsigned)tiles), dim3(256), 0, st, B, H, W, Ho, Wo, act, (const f16*)x, (unsigned)((long)B * 3 * H * W * 2), w, bias,
+                     (f16*)y, yCs);
+  EY_LAUNCH_CHECK("ey_stem_conv(mfma)");
+  return EY_OK;
+}
+
 template <typename TI, typename TO>
 static int stem_launch(int B, int Cin, int H, int W, int Cout, int act, const void* x, const float* w, const float* bias, void* y, int yCs, hipStream_t st) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -160,6 +241,15 @@ extern "C" int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int
   EY_CHECK(y_cstride >= Cout && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16), "stem: output view not 16-byte aligned");
   EY_CHECK(x_dtype != EY_F16 || (W % 2 == 0 && ey_aligned(x, 4)), "stem: f16 images need an even width (column pairs are fetched as 32-bit words)");
   hipStream_t st = (hipStream_t)stream;
+  static const bool stem_mfma_off = [] { const char* v = getenv("EY_STEM_MFMA"); return v && *v == '0'; }();
+  if (x_dtype == EY_F16 && y_dtype == EY_F16 && Cin == 3 && W % 8 == 0 && Cout <= 64 && ey_aligned(x, 16) && !stem_mfma_off && (long)B * 3 * H * W * 2 < (1L << 31)) {
+    switch (Cout / 16) {  // fp32-accumulated f16 products; the weights are rounded to f16 like every other conv of the f16 mode
+      case 1: return stem_mfma_launch<1>(B, H, W, act, x, w, bias, y, y_cstride, st);
+      case 2: return stem_mfma_launch<2>(B, H, W, act, x, w, bias, y, y_cstride, st);
+      case 3: return stem_mfma_launch<3>(B, H, W, act, x, w, bias, y, y_cstride, st);
+      case 4: return stem_mfma_launch<4>(B, H, W, act, x, w, bias, y, y_cstride, st);
+    }
+  }
   if (x_dtype == EY_F16 && y_dtype == EY_F16) return stem_launch<f16, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
   if (x_dtype == EY_F32 && y_dtype == EY_F16) return stem_launch<float, f16>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);
   if (x_dtype == EY_F16 && y_dtype == EY_F32) return stem_launch<f16, float>(B, Cin, H, W, Cout, act, x, w, bias, y, y_cstride, st);

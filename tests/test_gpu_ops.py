@@ -239,3 +239,19 @@ def test_linear_attention_mfma_agrees_with_f32_kernel(n_hw):
     q32.copy_(qkv.float())
     want = _ops.linear_attention(q32, 2).float().cpu()
     torch.testing.assert_close(got, want, rtol=1e-2, atol=2e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("h,w,c2", [(64, 64, 16), (96, 128, 16), (70, 200, 32), (33, 40, 48), (640, 640, 16)])
+def test_stem_mfma_agrees_with_f32_kernel(M, h, w, c2):
+    """f16 mode runs the MFMA stem (image patch in LDS, 2-byte tap gathers, one 16x16x32 MFMA per 16 pixels); f32 mode the direct
+    kernel.  Same f16-representable image and weights -> only summation order and the output rounding differ."""
+    torch.manual_seed(h + w + c2)
+    m = M.Conv(3, c2, 3, 2)
+    load_synth(m, "stemx")
+    m.fuse_bn()
+    with torch.no_grad():
+        m.conv.weight.copy_(m.conv.weight.half().float())
+    x = torch.rand(2, 3, h, w).half()
+    want = to_dev(m, torch.float32)(x.float().cuda()).float().cpu()
+    got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
+    torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
