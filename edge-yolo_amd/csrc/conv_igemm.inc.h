@@ -867,6 +867,77 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// Register-stationary 3x3 kernel for Cin == 16 (layer 1: 16->32 stride 2 at 320x320; the 16->8 sub-band convs): K = 144 is
+// nine 16-channel taps, i.e. nine v_mfma_f32_16x16x16_f16 per 16 pixels per 16 output channels, and the whole weight tile is
+// 9*NT two-register fragments -- it lives in registers.  A persistent wave walks 16-pixel row segments: 9 range-checked 8-byte
+// buffer loads per lane (a pixel's 16 channels = the 4 lanes of its k-groups = one 32-byte segment; zero padding for free; the next
+// segment's loads already in flight), 9*NT MFMAs, the shared epilogue.  No LDS, no barrier: these layers move 50-160 MB and were
+// bound by staging / per-tile overheads (2.3 TB/s), not by arithmetic.
+typedef f16 f16x4v __attribute__((ext_vector_type(4)));
+template <int NT, int S>
+__global__ __launch_bounds__(256) void conv3r_kernel(ConvP p) {
+  typedef f16 T;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int grp = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc((const T*)p.src[0] + (long)grp * p.srcG, p.srcBytes[0]);
+  f16x4v af[9][NT];
+  {
+    const T* wg = (const T*)p.w + (long)min(grp, p.wGmax) * p.wG;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) af[tap][nt] = *reinterpret_cast<const f16x4v*>(wg + (long)(nt * 16 + r) * p.Kpad + tap * 16 + 4 * g);
+  }
+  const int tilesX = (p.Wo + 15) >> 4;
+  const int ntile = p.B * p.Ho * tilesX;  // < 2^31 (host check)
+  const int nwave = gridDim.x * 4, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // each wave owns a CONTIGUOUS run of row segments: (image, row, segment) advance incrementally, no division per tile
+  const int per = (ntile + nwave - 1) / nwave;
+  int tile = wid * per;
+  const int tend = min(ntile, tile + per);
+  if (tile >= tend) return;
+  const int ch0 = g * 4 * NT;  // NT == NTpack, one channel tile
+  int row0 = tile / tilesX;
+  int ntx = tile - row0 * tilesX, nb = row0 / p.Ho, noy = row0 - nb * p.Ho;  // coordinates of the NEXT segment to issue
+  auto issue = [&](f16x4v (&bq)[9], int& b, int& oy, int& ox) {
+    b = nb; oy = noy; ox = ntx * 16 + r;
+    const int ix0 = ox * S - 1;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * S - 1 + ky;
+      const bool yok = iy >= 0 && iy < p.H && ox < p.Wo;
+      const int rowoff = ((b * p.H + iy) * p.W + ix0) * p.srcCs[0] + 4 * g;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ix0 + kx;
+        const unsigned off = (yok && ix >= 0 && ix < p.W) ? (unsigned)((rowoff + kx * p.srcCs[0]) * 2) : EY_OOB;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+        bq[ky * 3 + kx] = __builtin_bit_cast(f16x4v, t);
+      }
+    }
+    if (++ntx == tilesX) { ntx = 0; if (++noy == p.Ho) { noy = 0; ++nb; } }
+  };
+  f16x4v cur[9], nxt[9];
+  int b = 0, oy = 0, ox = 0, b2 = 0, oy2 = 0, ox2 = 0;
+  issue(cur, b, oy, ox);
+  for (; tile < tend; ++tile) {
+    if (tile + 1 < tend) issue(nxt, b2, oy2, ox2);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x16f16(af[tap][nt], cur[tap], acc[nt], 0, 0, 0);
+    if (ox < p.Wo) conv_epilogue<T, NT>(p, acc, ((long)b * p.Ho + oy) * p.Wo + ox, b, oy, ox, ch0, grp);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) cur[tap] = nxt[tap];
+    b = b2; oy = oy2; ox = ox2;
+  }
+}
+
+// ================================================================================================================
 // Lean pointwise kernel (1x1, stride 1, <= 2 sources) for maps up to ~80x80.  Measured on MI355X (tools/micro): a lone
 // wave retires about one instruction per 2.5 ns and a kernel launch costs 1.6 us, so for layers that move a few MB the
 // run time is the per-wave instruction count plus the memory round trips, not bandwidth.  Hence: no LDS, no barrier,
@@ -1184,6 +1255,7 @@ struct EyTune {
   long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
   long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 128); // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
+  long c3r = ey_env("EY_C3R", 1);                     // register-stationary 3x3 kernel for Cin == 16 (0 = off)
   long tile_minwg = ey_env("EY_TILE_MINWG", 400);     // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
   long tile_flat = ey_env("EY_TILE_FLAT", 1);         // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)
   long tile_mink = ey_env("EY_TILE_MINK", 0);         // 3x3 tile kernel for K = 9*Cin >= this (huge value = off)
@@ -1400,6 +1472,46 @@ static int dispatch_tile(ConvP p, int ngroup, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if (p.stride == 1) return nt == 4 ? tile_launch<T, 4, 1>(p, ngroup, st) : nt == 2 ? tile_launch<T, 2, 1>(p, ngroup, st) : tile_launch<T, 1, 1>(p, ngroup, st);
     return nt == 4 ? tile_launch<T, 4, 2>(p, ngroup, st) : nt == 2 ? tile_launch<T, 2, 2>(p, ngroup, st) : tile_launch<T, 1, 2>(p, ngroup, st);
+  }
+  return 0;
+}
+
+// ---- register-stationary 3x3 dispatch (Cin == 16)
+template <int NT, int S>
+static int c3r_launch(const ConvP& p, int ngroup, hipStream_t st) {
+  static int occ = 0;
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv3r_kernel<NT, S>, 256, 0) != hipSuccess || n < 1) n = 1;
+    occ = n > 4 ? 4 : n;
+  }
+  const long ntile = (long)p.B * p.Ho * ((p.Wo + 15) / 16);
+  if (ntile >= (1L << 31)) return 0;
+  long gx = (long)256 * occ / ngroup;
+  if (gx > (ntile + 3) / 4) gx = (ntile + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((conv3r_kernel<NT, S>), dim3((unsigned)gx, 1, (unsigned)ngroup), dim3(256), 0, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(c3r): %s", hipGetErrorString(e_));
+  g_last_variant = 7000 + NT * 10 + S;
+  return 1;
+}
+
+template <typename T>
+static int dispatch_c3r(ConvP p, int ngroup, hipStream_t st) {
+  if (sizeof(T) != 2 || !tune().c3r) return 0;
+  if (p.k != 3 || p.nsrc != 1 || p.srcUp[0] || p.srcC[0] != 16 || (p.srcCs[0] * 2) % 8) return 0;
+  if (p.stride != 2 && tune().c3r < 2) return 0;  // measured: wins for the stride-2 layer (68 -> 58 us), loses 10 % to the tile kernel at stride 1
+  const int ntp = conv_nt(p.Cout);
+  if (ntp > 2 || conv_cout_pad(p.Cout) != 16 * ntp) return 0;
+  const long npix = (long)p.B * p.H * p.W;
+  const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * 2L;
+  if (bytes >= (1L << 31) || p.srcG * 2L * (ngroup - 1) >= (1L << 31)) return 0;
+  p.srcBytes[0] = (unsigned)bytes;
+  p.NTpack = ntp;
+  if constexpr (sizeof(T) == 2) {
+    if (p.stride == 1) return ntp == 1 ? c3r_launch<1, 1>(p, ngroup, st) : c3r_launch<2, 1>(p, ngroup, st);
+    return ntp == 1 ? c3r_launch<1, 2>(p, ngroup, st) : c3r_launch<2, 2>(p, ngroup, st);
   }
   return 0;
 }
@@ -1640,6 +1752,8 @@ static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   if (pwr != 0) return pwr < 0 ? pwr : EY_OK;
   const int sm = dispatch_small<T>(p, ngroup, st);
   if (sm != 0) return sm < 0 ? sm : EY_OK;
+  const int cr = dispatch_c3r<T>(p, ngroup, st);
+  if (cr != 0) return cr < 0 ? cr : EY_OK;
   const int tl = dispatch_tile<T>(p, ngroup, st);
   if (tl != 0) return tl < 0 ? tl : EY_OK;
   const int halo = dispatch_halo<T>(p, ngroup, st);

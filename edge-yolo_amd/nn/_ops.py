@@ -169,7 +169,9 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         with rec:
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
             lv = L.lib().ey_conv_last_variant()
-            if lv >= 6000:
+            if lv >= 7000:
+                rec.kernel = f"conv3r_kernel<{lv % 1000 // 10},{lv % 10}>"
+            elif lv >= 6000:
                 rec.kernel = f"conv3_tile_kernel<{tn},{lv % 1000 // 10},{lv % 10}>"
             elif lv >= 5000:
                 rec.kernel = f"conv_pwr_kernel<{tn},{lv % 1000 // 10},{lv % 10}>"

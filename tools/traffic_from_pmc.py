@@ -26,6 +26,9 @@ def label_of(name):
     m = re.search(r"conv3_tile_kernelIDF16_Li(\d+)ELi(\d+)E", name)
     if m:
         return f"conv3_tile_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv3r_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"conv3r_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"conv3r_kernel<{m[1]},{m[2]}>"
     m = re.search(r"conv3_halo_kernelIDF16_Li(\d+)ELi(\d+)E", name)
     if m:
         return f"conv3_halo_kernel<f16,{m[1]},{m[2]}>"
