@@ -173,7 +173,7 @@ def main():
         ms = dt / a.steps * 1e3
         total_images = a.batch * world * a.steps
         out = {
-            "metric": "images/sec @ 640x640 fp16 (EdgeLine-YOLO detection forward path: backbone + DWT neck + GFLv2 head decode + batched NMS)",
+            "metric": f"images/sec @ {a.imgsz}x{a.imgsz} {'fp16' if a.dtype == 'f16' else 'fp32'} (EdgeLine-YOLO detection forward path: backbone + DWT neck + GFLv2 head decode + batched NMS)",
             "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",

@@ -58,6 +58,7 @@ SIGNATURES = {
     "ey_dsconv_toeplitz_bytes": (_sz, [_i, _i]),
     "ey_dsconv_pack_toeplitz": (_i, [_i, _i, _vp, _vp, _sz]),
     "ey_dsconv_tz": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ey_dsconv_last_variant": (_i, []),
     "ey_dwt_haar": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ey_sppf_pool": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ey_copy_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

@@ -403,6 +403,110 @@ __global__ __launch_bounds__(256) void softattn_kernel(int N, int heads, int kd,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA form of the softmax attention core (f16 mode, key_dim 32, head_dim 64, N <= 416: the C2PSA block of the YOLO11 baseline
+// at 640x640).  The VALU kernel above was 35 % of the YOLO11n step (0.85 ms).  One 512-thread workgroup per (image, head); K and V
+// of the head are staged once in LDS; a wave owns 16 queries at a time, flash-attention style but with all scores in registers:
+//   S^T = K Q^T            A = K rows (keys) from LDS, B = Q (16-byte loads, k = the 32 key channels): lane = query, 4 keys per block
+//   softmax over keys      per-lane over its 4*NKB values, then across the 4 lanes that share a query (2 shuffles)
+//   Y^T = V^T P^T          contraction over keys in the ORDER the scores already sit in the registers (k-slot 8g+j of a 32-key step
+//                          = key 32s + 16(j>>2) + 4g + (j&3)), so P needs no cross-lane movement; V^T fragments by 2-byte LDS gathers
+#define SM_MAXKS 13        // 32-key steps: N <= 416
+#define SM_KLS 40          // LDS row stride of K (elements)
+#define SM_VLS 72          // LDS row stride of V
+template <int NKS>
+__global__ __launch_bounds__(512) void softattn_mfma_kernel(int N, int heads, float scale, const f16* __restrict__ qkv, int qCs, f16* __restrict__ y, int yCs) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  f16* Ks = reinterpret_cast<f16*>(smem);      // [NKS*32][SM_KLS]
+  f16* Vs = Ks + NKS * 32 * SM_KLS;            // [NKS*32][SM_VLS]
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const f16* base = qkv + (long)b * N * qCs + h * 128;  // [q 32 | k 32 | v 64]
+  for (int v = tid; v < NKS * 32 * 4; v += 512) {
+    const int n = v >> 2, cv = v & 3;
+    Vec8<f16> t;
+    if (n < N) t.load(base + (long)n * qCs + 32 + cv * 8);
+    else t.zero();
+    t.store(Ks + n * SM_KLS + cv * 8);
+  }
+  for (int v = tid; v < NKS * 32 * 8; v += 512) {
+    const int n = v >> 3, cv = v & 7;
+    Vec8<f16> t;
+    if (n < N) t.load(base + (long)n * qCs + 64 + cv * 8);
+    else t.zero();
+    t.store(Vs + n * SM_VLS + cv * 8);
+  }
+  __syncthreads();
+  for (int qb = wave; qb * 16 < N; qb += 8) {
+    const int n = qb * 16 + r;
+    Vec8<f16> qf;
+    if (n < N) qf.load(base + (long)n * qCs + 8 * g);
+    else qf.zero();
+    // scores: S[kb][t] = q(n) . k(16 kb + 4g + t)
+    f32x4 S[2 * NKS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2 * NKS; ++kb) {
+      Vec8<f16> kf;
+      kf.load(Ks + (kb * 16 + r) * SM_KLS + 8 * g);
+      S[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf.v, qf.v, (f32x4)0.f, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (kb * 16 + 4 * g + t >= N) S[kb][t] = -INFINITY;  // padded keys
+        mx = fmaxf(mx, S[kb][t]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2 * NKS; ++kb)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { S[kb][t] = __expf((S[kb][t] - mx) * scale); sum += S[kb][t]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    // y^T[c][n] = sum_key v[key][c] p[n][key]
+    f32x4 acc[4] = {(f32x4)0.f, (f32x4)0.f, (f32x4)0.f, (f32x4)0.f};
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      Vec8<f16> pf;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { pf.v[t] = (f16)(S[2 * s][t] * inv); pf.v[4 + t] = (f16)(S[2 * s + 1][t] * inv); }
+      const f16* vp = Vs + (32 * s + 4 * g) * SM_VLS + r;
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        Vec8<f16> vf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vf.v[j] = vp[(16 * (j >> 2) + (j & 3)) * SM_VLS + cb * 16];
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf.v, pf.v, acc[cb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the gathers of later steps from being hoisted over the 100+ live score registers
+    }
+    if (n < N) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const f16x4 o = {(f16)acc[cb][0], (f16)acc[cb][1], (f16)acc[cb][2], (f16)acc[cb][3]};
+        *reinterpret_cast<f16x4*>(y + ((long)b * N + n) * yCs + h * 64 + cb * 16 + 4 * g) = o;
+      }
+    }
+  }
+}
+
+template <int NKS>
+static int softattn_mfma_launch(int B, int N, int heads, float scale, const void* qkv, int qCs, void* y, int yCs, hipStream_t st) {
+  const size_t lds = (size_t)NKS * 32 * (SM_KLS + SM_VLS) * sizeof(f16);
+  static bool attr = false;
+  if (!attr && lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)softattn_mfma_kernel<NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    attr = true;
+  }
+  hipLaunchKernelGGL((softattn_mfma_kernel<NKS>), dim3(B * heads), dim3(512), lds, st, N, heads, scale, (const f16*)qkv, qCs, (f16*)y, yCs);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_softmax_attention(mfma): %s", hipGetErrorString(e_));
+  return 1;
+}
+
 extern "C" int ey_softmax_attention(int dtype, int B, int N, int heads, int kd, int hd, float scale, const void* qkv, int qkv_cstride, void* y, int y_cstride,
                                     ey_stream_t stream) {
   EY_CHECK(qkv && y, "softmax_attention: null pointer");
@@ -411,6 +515,18 @@ extern "C" int ey_softmax_attention(int dtype, int B, int N, int heads, int kd, 
   if (kd > 64) return ey_set_error(EY_EUNSUPPORTED, "softmax_attention: key_dim %d > 64", kd);
   EY_CHECK(qkv_cstride >= heads * (2 * kd + hd) && y_cstride >= heads * hd, "softmax_attention: cstride");
   const int es = dtype == EY_F16 ? 2 : 4;
+  static const bool sm_mfma_off = [] { const char* v = getenv("EY_SOFTATTN_MFMA"); return v && *v == '0'; }();
+  if (dtype == EY_F16 && kd == 32 && hd == 64 && N <= 32 * SM_MAXKS && !sm_mfma_off && (qkv_cstride * 2) % 16 == 0 && ey_aligned(qkv, 16) && (y_cstride * 2) % 8 == 0 &&
+      ey_aligned(y, 8)) {
+    const int nks = (N + 31) / 32;
+    int rc = 0;
+    // the score registers are sized at compile time: 4 variants cover N <= 128 / 256 / 320 / 416
+    if (nks <= 4) rc = softattn_mfma_launch<4>(B, N, heads, scale, qkv, qkv_cstride, y, y_cstride, (hipStream_t)stream);
+    else if (nks <= 8) rc = softattn_mfma_launch<8>(B, N, heads, scale, qkv, qkv_cstride, y, y_cstride, (hipStream_t)stream);
+    else if (nks <= 10) rc = softattn_mfma_launch<10>(B, N, heads, scale, qkv, qkv_cstride, y, y_cstride, (hipStream_t)stream);
+    else rc = softattn_mfma_launch<13>(B, N, heads, scale, qkv, qkv_cstride, y, y_cstride, (hipStream_t)stream);
+    if (rc != 0) return rc < 0 ? rc : EY_OK;
+  }
   const size_t lds_base = (4 * (size_t)N + 4 * 64) * 4;
   if (lds_base > 160 * 1024) return ey_set_error(EY_EUNSUPPORTED, "softmax_attention: N=%d needs %zu B of LDS", N, lds_base);
   const bool k_lds = lds_base + (size_t)N * kd * es <= 160 * 1024;

@@ -11,6 +11,7 @@
 // The intermediate (B,C,H,W) tensor of the unfused form never touches HBM: x is read once, y written once.
 #include "common.h"
 
+static thread_local int g_ds_variant = 0;  // kernel the last ey_dsconv / ey_dsconv_tz launched: 1 LDS tile, 2 register strip, 3 Toeplitz MFMA
 struct DsP {
   int B, H, W, Cin, Cout, act;
   const void* x; int xCs; unsigned xBytes;
@@ -522,6 +523,7 @@ static int ds_launch(DsP p, hipStream_t st) {
   long gx = (long)256 * per_cu / ntn;
   if (gx < 1) gx = 1;
   if (gx > p.ntile) gx = p.ntile;
+  g_ds_variant = 1;
   hipLaunchKernelGGL((dsconv_kernel<T, K, NT>), dim3((unsigned)gx, ntn), dim3(256), lds, st, p);
   EY_LAUNCH_CHECK("ey_dsconv");
   return EY_OK;
@@ -554,6 +556,7 @@ static int ds_strip_launch(const DsP& p, hipStream_t st) {
   const long nstrip = (long)p.B * p.H * ((p.W + P - 1) / P);
   const long nwave = (nstrip + 15) / 16;
   const size_t lds = (size_t)K * K * p.Cin * sizeof(f16);
+  g_ds_variant = 2;
   hipLaunchKernelGGL((dsconv_strip_kernel<K, NT, KS, P>), dim3((unsigned)((nwave + 3) / 4)), dim3(256), lds, st, p);
   hipError_t e_ = hipGetLastError();
   if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_dsconv(strip): %s", hipGetErrorString(e_));
@@ -591,6 +594,8 @@ static int ds_strip_dispatch(const DsP& p, int k, hipStream_t st) {
   return ds_strip_k<7>(p, nt, ks, st);
 }
 
+extern "C" int ey_dsconv_last_variant(void) { return g_ds_variant; }
+
 // ---- Toeplitz fragments: out[((c*k + ky)*64 + lane)*8 + t] = w[ky][kx = 8g + t - i][c], lane = (i = lane & 15, g = lane >> 4)
 extern "C" size_t ey_dsconv_toeplitz_bytes(int C, int k) { return (size_t)C * k * 64 * 8 * sizeof(f16); }
 extern "C" int ey_dsconv_pack_toeplitz(int C, int k, const float* w_kkc_host, void* out_host, size_t out_bytes) {
@@ -621,6 +626,7 @@ static int ds_tz_launch(DsP p, const void* tz, hipStream_t st) {
   }
   long gx = 256L * occ;
   if (gx > p.ntile) gx = p.ntile;
+  g_ds_variant = 3;
   hipLaunchKernelGGL((dsconv_tz_kernel<K, NT, CPW>), dim3((unsigned)gx), dim3(512), lds, st, p, (const f16*)tz);
   EY_LAUNCH_CHECK("ey_dsconv_tz");
   return EY_OK;

@@ -286,13 +286,16 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
     if res is not None:
         res = L.as_nhwc(res)
     try:
-      with _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}"):
+      rec = _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}")
+      with rec:
         tail = (dwb.data_ptr() if dwb is not None else None, dw_act, wp.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out),
                 res.data_ptr() if res is not None else None, L.cstride(res) if res is not None else 0, L.stream())
         if tz is not None:
             L.check(L.lib().ey_dsconv_tz(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), tz.data_ptr(), *tail), "ey_dsconv_tz")
         else:
             L.check(L.lib().ey_dsconv(L.dtype_code(x.dtype), B, H, W, c, cout, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(), *tail), "ey_dsconv")
+        if TRACE is not None:
+            rec.kernel = {2: f"dsconv_strip_kernel<{k}>", 3: f"dsconv_tz_kernel<{k}>"}.get(L.lib().ey_dsconv_last_variant(), rec.kernel)
     except NotImplementedError:  # EY_EUNSUPPORTED is returned before anything is launched (tile does not fit LDS): two-kernel form
         return None
     return out

@@ -8,6 +8,9 @@ import torch
 from .nn import _ops
 
 
+_SPIN_CYCLES = 60_000_000  # ~25-30 ms at 2.1-2.4 GHz: longer than the host needs to enqueue one instrumented step
+
+
 class Trace:
     def __init__(self):
         self.records = []  # (kernel, alg_bytes, alg_flops, start_event, end_event)
@@ -73,7 +76,12 @@ def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
     torch.cuda.synchronize()
     with trace() as t:
         for _ in range(steps):
+            # A spin kernel first, so that the host enqueues the whole step (launches + events) while the GPU is still busy:
+            # the events then bracket back-to-back kernel executions.  Without it every bracket also contains the host's
+            # ~6 us submission gap, which doubles the apparent time of the many 5-10 us launches (and disagrees with rocprofv3).
+            torch.cuda._sleep(_SPIN_CYCLES)
             step_fn()
+            torch.cuda.synchronize()
     agg = t.summary()
     total = sum(a["ms"] for a in agg.values())
     # The roofline is priced for the dominant kernel of the FORWARD stage.  The NMS stage (key build + per-image greedy

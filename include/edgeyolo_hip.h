@@ -138,6 +138,10 @@ int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, int k, int a
                  const void* w_dw_kkc, const void* w_dw_toeplitz, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias,
                  void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream);
 
+/* Kernel the last ey_dsconv / ey_dsconv_tz on this thread launched (profiling labels): 1 = dsconv_kernel (LDS tile),
+ * 2 = dsconv_strip_kernel (register strip), 3 = dsconv_tz_kernel (Toeplitz MFMA). */
+int ey_dsconv_last_variant(void);
+
 /* ---- K4: single-level 2-D Haar analysis (_PywtDWT2D.forward, block.py:3619-3642).
  * x [B,H,W,C] -> y [B,H/2,W/2,4C] with channel blocks LL|LH|HL|HH; odd H/W floor like the stride-2 conv. */
 int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y, int y_cstride,

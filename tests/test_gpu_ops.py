@@ -255,3 +255,20 @@ def test_stem_mfma_agrees_with_f32_kernel(M, h, w, c2):
     want = to_dev(m, torch.float32)(x.float().cuda()).float().cpu()
     got = to_dev(m, torch.float16)(x.cuda()).float().cpu()
     torch.testing.assert_close(got, want, rtol=2e-3, atol=2e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("n_hw", [(20, 20), (13, 9), (16, 16), (7, 5), (20, 19)])
+def test_softmax_attention_mfma_agrees_with_f32_kernel(n_hw):
+    """f16 mode runs the MFMA softmax-attention kernel (key_dim 32, head_dim 64, N <= 416), f32 mode the VALU kernel; same
+    f16-representable qkv -> they differ by the f16 rounding of the probabilities (the reference's half-precision matmul operand)."""
+    from edge_yolo_amd.nn import _ops
+    from edge_yolo_amd import _lib as L
+    h, w = n_hw
+    torch.manual_seed(h * 10 + w)
+    qkv = L.empty_nhwc(3, 256, h, w, torch.float16, "cuda")  # 2 heads x (32 + 32 + 64)
+    qkv.copy_((torch.randn(3, 256, h, w) * 1.2).half())
+    got = _ops.softmax_attention(qkv, 2, 32, 64, 32 ** -0.5).float().cpu()
+    q32 = L.empty_nhwc(3, 256, h, w, torch.float32, "cuda")
+    q32.copy_(qkv.float())
+    want = _ops.softmax_attention(q32, 2, 32, 64, 32 ** -0.5).float().cpu()
+    torch.testing.assert_close(got, want, rtol=1e-2, atol=3e-3 * float(want.abs().max()))

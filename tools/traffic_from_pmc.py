@@ -35,9 +35,17 @@ def label_of(name):
     m = re.search(r"conv_small_kernelIDF16_Li(\d+)ELi(\d+)E", name)
     if m:
         return f"conv_small_kernel<f16,{m[1]},{m[2]}>"
-    m = re.search(r"dsconv_kernelIDF16_Li(\d+)E", name) or re.search(r"dsconv_strip_kernel(?:ILi|<)(\d+)", name)
+    m = re.search(r"dsconv_strip_kernel(?:ILi|<)(\d+)", name)
+    if m:
+        return f"dsconv_strip_kernel<{m[1]}>"
+    m = re.search(r"dsconv_tz_kernel(?:ILi|<)(\d+)", name)
+    if m:
+        return f"dsconv_tz_kernel<{m[1]}>"
+    m = re.search(r"dsconv_kernelIDF16_Li(\d+)E", name)
     if m:
         return f"dsconv_kernel<{m[1]}>"
+    if "stem_mfma" in name:
+        return "stem_kernel"
     m = re.search(r"dwconv_kernelIDF16_Li(\d+)E", name)
     if m:
         return f"dwconv_kernel<{m[1]}>"
