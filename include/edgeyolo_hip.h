@@ -91,7 +91,9 @@ int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream);
 int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_single_source, long M, int ngroup);
 /* Code of the kernel the last ey_conv2d on this thread launched when ey_conv_variant() does not describe it (else 0):
  * 4000 + NT*10 + nsrc = conv_pw_kernel<T,NT,...> (lean pointwise kernel for small maps); 5000 + NT*10 + KS =
- * conv_pwr_kernel<T,NT,KS,...> (register-stationary pointwise kernel for large maps).  Profiling labels only. */
+ * conv_pwr_kernel<T,NT,KS,...> (register-stationary pointwise kernel for large maps); 6000 + NT*10 + stride =
+ * conv3_tile_kernel<T,NT,S,...> (3x3 LDS tile kernel); 7000 + NT*10 + stride = conv3r_kernel<NT,S> (register-stationary
+ * 3x3 kernel for Cin = 16).  Profiling labels only. */
 int ey_conv_last_variant(void);
 /* NT the weights of a Cout-channel conv are packed with (row permutation of ey_conv_pack_weight). */
 int ey_conv_pack_nt(int Cout);
