@@ -51,6 +51,9 @@ SIGNATURES = {
     "ey_conv_variant": (_i, [_i, _i, _i, _i, _i, _i, C.c_long, _i]),
     "ey_conv_last_variant": (_i, []),
     "ey_conv_pack_nt": (_i, [_i]),
+    "ey_conv_chain_klen": (_i, [_i]),
+    "ey_conv_chain_kperm": (_i, [_i, _vp, _i]),
+    "ey_conv_pw_chain": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_conv2d_direct": (_i, [C.POINTER(ConvDirectDesc), _vp]),
     "ey_stem_conv": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ey_dwconv": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),

@@ -1166,6 +1166,103 @@ __global__ __launch_bounds__(256) void conv_pwr_kernel(ConvP p) {
   }
 }
 
+// ================================================================================================================
+// Two chained pointwise convs in ONE kernel, registers only (f16; the last two 1x1 convs of the Detect class tower):
+//     y = act2( W2 . act1( W1 . x + b1 ) + b2 )
+// After the first GEMM lane (pixel r, group g) holds 4*NT1 consecutive mid channels of its pixel -- and a contraction may run over
+// its index in ANY order as long as both operands agree.  So the second GEMM's k-slot (step s, 8g + j) is DEFINED as mid channel
+// g*4*NT1 + 8s + j: the activated, f16-rounded values of a lane are its own B fragments, nothing moves between lanes, no LDS; W2 is
+// packed by the ordinary ey_conv_pack_weight() after its input columns were permuted accordingly (ey_conv_chain_kperm).
+// Persistent waves, both weight tiles and both biases in registers, next tile's pixels in flight (as conv_pwr_kernel).
+struct ChainP {
+  const void* w2; const float* b2; int act2, Cout2, Kpad2;
+  void* y2; int y2Cs;
+};
+template <int NT1, int KS1, int NT2>
+__global__ __launch_bounds__(256) void conv_pw2_kernel(ConvP p, ChainP q) {
+  typedef f16 T;
+  constexpr int KS2 = (4 * NT1 + 7) / 8;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int M = p.B * p.Ho * p.Wo;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), nwave = gridDim.x * 4;
+  const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(p.src[0], p.srcBytes[0]);
+  const int C0 = p.srcC[0];
+  Vec8<T> a1[KS1][NT1], a2[KS2][NT2];
+  {
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(p.w, (unsigned)(16 * NT1 * p.Kpad * 2));
+    const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * 2);
+#pragma unroll
+    for (int t = 0; t < KS1; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) BufLoad8<T>::load(a1[t][nt], rw, wvoff, (nt * 16 * p.Kpad + t * 32) * 2);
+    const __amdgpu_buffer_rsrc_t rw2 = ey_rsrc(q.w2, (unsigned)(16 * NT2 * q.Kpad2 * 2));
+    const unsigned wvoff2 = (unsigned)((r * q.Kpad2 + 8 * g) * 2);
+#pragma unroll
+    for (int t = 0; t < KS2; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) BufLoad8<T>::load(a2[t][nt], rw2, wvoff2, (nt * 16 * q.Kpad2 + t * 32) * 2);
+  }
+  const int ch1 = g * 4 * NT1, ch2 = g * 4 * NT2;
+  float b1[4 * NT1], b2[4 * NT2];
+#pragma unroll
+  for (int i = 0; i < 4 * NT1; ++i) b1[i] = (p.bias && ch1 + i < p.Cout) ? p.bias[ch1 + i] : 0.f;
+#pragma unroll
+  for (int i = 0; i < 4 * NT2; ++i) b2[i] = (q.b2 && ch2 + i < q.Cout2) ? q.b2[ch2 + i] : 0.f;
+  bool cok[KS1];
+#pragma unroll
+  for (int t = 0; t < KS1; ++t) cok[t] = (32 * t + 8 * g) < C0;
+  auto issue = [&](int tile, Vec8<T> (&bf)[KS1]) {
+    const int m = tile * 16 + r;
+    const unsigned v0 = m < M ? (unsigned)((m * p.srcCs[0] + 8 * g) * 2) : EY_OOB;
+#pragma unroll
+    for (int t = 0; t < KS1; ++t) BufLoad8<T>::load(bf[t], rs0, cok[t] ? v0 : EY_OOB, t * 64);
+  };
+  Vec8<T> cur[KS1], nxt[KS1];
+  int tile = wave_id;
+  if (tile < (int)p.ntile) issue(tile, cur);
+  for (; tile < (int)p.ntile; tile += nwave) {
+    if (tile + nwave < (int)p.ntile) issue(tile + nwave, nxt);
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) acc[nt] = (f32x4)0.f;
+#pragma unroll
+    for (int t = 0; t < KS1; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT1; ++nt) acc[nt] = mma16(a1[t][nt], cur[t], acc[nt]);
+    // mid activations (rounded to f16 like the tensor the unfused form writes) = B fragments of the second GEMM
+    Vec8<T> mid[KS2];
+#pragma unroll
+    for (int t = 0; t < KS2; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = 8 * t + j;
+        mid[t].set(j, (idx < 4 * NT1 && ch1 + idx < p.Cout) ? ey_act(acc[idx >> 2][idx & 3] + b1[idx], p.act) : 0.f);
+      }
+    f32x4 acc2[NT2];
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) acc2[nt] = (f32x4)0.f;
+#pragma unroll
+    for (int t = 0; t < KS2; ++t)
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) acc2[nt] = mma16(a2[t][nt], mid[t], acc2[nt]);
+    const int m = tile * 16 + r;
+    if (m < M) {
+      T* yp = (T*)q.y2 + (long)m * q.y2Cs + ch2;
+#pragma unroll
+      for (int nt = 0; nt < NT2; ++nt) {
+        if (ch2 + 4 * nt + 4 <= q.Cout2) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = ey_act(acc2[nt][j] + b2[4 * nt + j], q.act2);
+          store4(yp + 4 * nt, v);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KS1; ++t) cur[t] = nxt[t];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 static int conv_nt(int Cout) {  // channels per block tile / 16
   if (Cout <= 16) return 1;
@@ -1826,6 +1923,57 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   g_last_variant = 0;
   return d->dtype == EY_F16 ? ey_conv2d_run_f16(p, ngroup, st) : ey_conv2d_run_f32(p, ngroup, st);
+}
+
+// ---- chained pointwise pair (see conv_pw2_kernel)
+extern "C" int ey_conv_chain_kperm(int Cmid, int* perm, int perm_len) {
+  const int nt1 = conv_nt(Cmid);
+  EY_CHECK(Cmid == 16 * nt1 && perm, "chain_kperm: Cmid=%d must be a whole channel tile (16, 32, 64, 80, 128)", Cmid);
+  const int ks2 = (4 * nt1 + 7) / 8;
+  EY_CHECK(perm_len == 32 * ks2, "chain_kperm: perm_len must be %d", 32 * ks2);
+  for (int s2 = 0; s2 < ks2; ++s2)
+    for (int g = 0; g < 4; ++g)
+      for (int j = 0; j < 8; ++j) {
+        const int idx = 8 * s2 + j;
+        perm[32 * s2 + 8 * g + j] = idx < 4 * nt1 ? g * 4 * nt1 + idx : -1;  // -1: zero column
+      }
+  return EY_OK;
+}
+extern "C" int ey_conv_chain_klen(int Cmid) { const int nt1 = conv_nt(Cmid); return Cmid == 16 * nt1 ? 32 * ((4 * nt1 + 7) / 8) : 0; }
+
+template <int NT1, int KS1, int NT2>
+static int pw2_launch(const ConvP& p, const ChainP& q, hipStream_t st) {
+  static int occ = 0;
+  if (!occ) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_pw2_kernel<NT1, KS1, NT2>, 256, 0) != hipSuccess || n < 1) n = 1;
+    occ = n > 4 ? 4 : n;
+  }
+  long gx = 256L * occ;
+  if (gx > (p.ntile + 3) / 4) gx = (p.ntile + 3) / 4;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((conv_pw2_kernel<NT1, KS1, NT2>), dim3((unsigned)gx), dim3(256), 0, st, p, q);
+  EY_LAUNCH_CHECK("ey_conv_pw_chain");
+  return EY_OK;
+}
+
+extern "C" int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmid, int Cout, const void* x, int x_cstride, const void* w1_packed, const float* b1,
+                                int act1, const void* w2_packed, const float* b2, int act2, void* y, int y_cstride, ey_stream_t stream) {
+  EY_CHECK(dtype == EY_F16, "conv_pw_chain: f16 only");
+  EY_CHECK(x && w1_packed && w2_packed && y && B > 0 && H > 0 && W > 0, "conv_pw_chain: bad arguments");
+  const int nt1 = conv_nt(Cmid), nt2 = conv_nt(Cout), ks1 = (Cin + 31) / 32;
+  if (!(nt1 == 5 && Cmid == 80 && nt2 == 5 && Cout <= 80 && Cout % 4 == 0 && ks1 == 3 && Cin % 8 == 0))
+    return ey_set_error(EY_EUNSUPPORTED, "conv_pw_chain: built for Cin 72..96 -> 80 -> <= 80 (got %d -> %d -> %d)", Cin, Cmid, Cout);
+  EY_CHECK(x_cstride >= Cin && (x_cstride * 2) % 16 == 0 && ey_aligned(x, 16) && y_cstride >= Cout && (y_cstride * 2) % 8 == 0 && ey_aligned(y, 8), "conv_pw_chain: view alignment");
+  const long M = (long)B * H * W, bytes = ((M - 1) * x_cstride + Cin) * 2L;
+  EY_CHECK(bytes < (1L << 31) && M < (1L << 27), "conv_pw_chain: tensor too large");
+  ConvP p;
+  p.B = B; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.Cout = Cmid; p.act = act1; p.nsrc = 1;
+  p.src[0] = x; p.srcC[0] = Cin; p.srcCs[0] = x_cstride; p.srcBytes[0] = (unsigned)bytes;
+  p.w = w1_packed; p.bias = b1; p.Kpad = conv_kpad(Cin, 1); p.ntile = (M + 15) / 16;
+  ChainP q;
+  q.w2 = w2_packed; q.b2 = b2; q.act2 = act2; q.Cout2 = Cout; q.Kpad2 = conv_kpad(ey_conv_chain_klen(Cmid), 1); q.y2 = y; q.y2Cs = y_cstride;
+  return pw2_launch<5, 3, 5>(p, q, (hipStream_t)stream);
 }
 
 // Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only): kind*1000 + NT*10 + MT,

@@ -182,6 +182,46 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
     return out
 
 
+def conv_pw_chain(mod, x, fold1, act1, fold2, act2, out):
+    """y = act2(W2 . act1(W1 . x + b1) + b2) in ONE kernel (two chained 1x1 convs, registers only).  Returns None when the shape is
+    outside the fused kernel (the caller then runs the two convs)."""
+    L.require_device(x, "conv_pw_chain")
+    x = L.as_nhwc(x)
+    B, cin, H, W = x.shape
+    if x.dtype != torch.float16 or cin % 8 or (L.cstride(x) * 2) % 16 or x.data_ptr() % 16:
+        return None
+
+    def build():
+        w1, b1 = fold1()
+        w2, b2 = fold2()
+        cmid, cout = w1.shape[0], w2.shape[0]
+        klen = L.lib().ey_conv_chain_klen(cmid)
+        if not klen or w1.shape[2] != 1 or w2.shape[2] != 1 or w2.shape[1] != cmid or not (cmid == 80 and 64 < cout <= 80 and cout % 4 == 0 and 72 <= cin <= 96):
+            return False  # cached: this pair runs as two convs
+        perm = (ctypes.c_int * klen)()
+        L.check(L.lib().ey_conv_chain_kperm(cmid, perm, klen), "ey_conv_chain_kperm")
+        idx = torch.tensor(list(perm), dtype=torch.long)
+        w2f = w2.detach().float().cpu()
+        w2p = torch.zeros((cout, klen, 1, 1))
+        w2p[:, idx >= 0] = w2f[:, idx[idx >= 0]]  # second contraction in the order the first GEMM leaves its results in the registers
+        dev = x.device
+        return (pack_conv_weight(w1, x.dtype, dev), b1.to(dev).float().contiguous() if b1 is not None else None, pack_conv_weight(w2p, x.dtype, dev),
+                b2.to(dev).float().contiguous() if b2 is not None else None, cmid, cout)
+
+    packed = mod._packed(_dev_key(x, "pwchain"), build)
+    if packed is False:
+        return None
+    w1p, b1, w2p, b2, cmid, cout = packed
+    if not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, H, W) or out.dtype != x.dtype:
+        raise ValueError("conv_pw_chain: out= must be an NHWC view of the output shape")
+    M = B * H * W
+    with _tr("conv_pw2_kernel", _nb(x, out) + (cmid * cin + cout * cmid) * 2, 2.0 * M * (cmid * cin + cout * cmid), note=f"{cin}->{cmid}->{cout} {H}x{W}"):
+        L.check(L.lib().ey_conv_pw_chain(L.dtype_code(x.dtype), B, H, W, cin, cmid, cout, x.data_ptr(), L.cstride(x), w1p.data_ptr(),
+                                         b1.data_ptr() if b1 is not None else None, act1, w2p.data_ptr(), b2.data_ptr() if b2 is not None else None, act2,
+                                         out.data_ptr(), L.cstride(out), L.stream()), "ey_conv_pw_chain")
+    return out
+
+
 def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""):
     L.require_device(x, "conv2d_direct")
     if res is not None:

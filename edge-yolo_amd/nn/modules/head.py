@@ -19,6 +19,7 @@ __all__ = ("Detect", "GF2Detect", "GFLHeadv2_uniH")
 
 
 _HEAD_STREAMS = os.environ.get("EY_HEAD_STREAMS", "1") != "0"
+_CHAIN = os.environ.get("EY_HEAD_CHAIN", "1") != "0"  # fuse the last two 1x1 convs of the class tower (ey_conv_pw_chain)
 # developer override: stream index (0 = the caller's stream) of each tower in order (level0 box, level0 cls, level1 box, ...)
 _HEAD_MAP = [int(v) for v in os.environ["EY_HEAD_MAP"].split(",")] if os.environ.get("EY_HEAD_MAP") else None
 
@@ -88,9 +89,23 @@ class Detect(nn.Module):
         """class logits -> raw[:, 64:]."""
         c = self.cv3[i]
         t = x
+        out = raw[:, 4 * self.reg_max:]
+        last = c[-2]
+        # non-legacy tower (head.py:68-70): ... -> DWConv -> Conv(c3,c3,1)+SiLU -> nn.Conv2d(c3,nc,1): the last two 1x1 convs run as ONE
+        # register-only kernel when the shape fits (ey_conv_pw_chain), the intermediate (B,c3,H,W) tensor never exists
+        if (_CHAIN and isinstance(last, nn.Sequential) and len(last) == 2 and isinstance(last[0], DWConv) and isinstance(last[1], Conv)
+                and last[1].conv.kernel_size == (1, 1) and isinstance(last[1].act, nn.SiLU) and x.dtype == torch.float16):
+            for j in range(len(c) - 2):
+                t = c[j](t)
+            t = last[0](t)
+            tail = c[-1]
+            if ops.conv_pw_chain(self._tail(tail), t, last[1].folded, L.ACT_SILU, lambda: fold_bn(tail.weight, tail.bias, None), L.ACT_NONE, out) is not None:
+                return
+            self._tail(tail).run(last[1](t), out)
+            return
         for j in range(len(c) - 1):
             t = c[j](t)  # (self._dw_pw fuses DWConv+Conv into one kernel; measured slower than the two kernels at these widths)
-        self._tail(c[-1]).run(t, raw[:, 4 * self.reg_max:])
+        self._tail(c[-1]).run(t, out)
 
     def _towers(self, i, x, raw):
         self._box_tower(i, x, raw)

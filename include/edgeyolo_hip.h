@@ -95,6 +95,15 @@ int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_s
  * conv3_tile_kernel<T,NT,S,...> (3x3 LDS tile kernel); 7000 + NT*10 + stride = conv3r_kernel<NT,S> (register-stationary
  * 3x3 kernel for Cin = 16).  Profiling labels only. */
 int ey_conv_last_variant(void);
+/* ---- two chained pointwise convs in one kernel, registers only: y = act2(W2 . act1(W1 . x + b1) + b2) -- the last two 1x1 convs
+ * of the Detect class tower (Conv(c3,c3,1)+SiLU, nn.Conv2d(c3,nc,1); head.py:68-70).  w1_packed = ey_conv_pack_weight(Cmid, Cin, 1);
+ * w2_packed = ey_conv_pack_weight(Cout, ey_conv_chain_klen(Cmid), 1) of W2 with its INPUT columns gathered by ey_conv_chain_kperm
+ * (perm[k'] = mid channel feeding k-slot k', -1 = zero column): the second contraction runs in the order the first GEMM leaves its
+ * results in the registers.  f16 only; built for Cin 72..96, Cmid = 80, Cout <= 80; EY_EUNSUPPORTED otherwise (run the two convs). */
+int ey_conv_chain_klen(int Cmid);
+int ey_conv_chain_kperm(int Cmid, int* perm_host, int perm_len);
+int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmid, int Cout, const void* x, int x_cstride, const void* w1_packed,
+                     const float* b1, int act1, const void* w2_packed, const float* b2, int act2, void* y, int y_cstride, ey_stream_t stream);
 /* NT the weights of a Cout-channel conv are packed with (row permutation of ey_conv_pack_weight). */
 int ey_conv_pack_nt(int Cout);
 

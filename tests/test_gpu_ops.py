@@ -272,3 +272,31 @@ def test_softmax_attention_mfma_agrees_with_f32_kernel(n_hw):
     q32.copy_(qkv.float())
     want = _ops.softmax_attention(q32, 2, 32, 64, 32 ** -0.5).float().cpu()
     torch.testing.assert_close(got, want, rtol=1e-2, atol=3e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(80, 80, 40, 40), (96, 80, 23, 17), (72, 68, 20, 20), (80, 80, 80, 80)])
+def test_pointwise_chain_kernel_agrees_with_two_f32_convs(M, cin, cout, h, w):
+    """ey_conv_pw_chain (f16: two 1x1 convs in one register-only kernel, the second contraction in the first GEMM's register order)
+    against the same two convs run one after the other by the exact-f32 kernels on the same f16-representable weights / input."""
+    import torch.nn as nn
+    from edge_yolo_amd.nn import _ops
+    from edge_yolo_amd import _lib as L
+    from edge_yolo_amd.nn.modules.conv import fold_bn
+    from edge_yolo_amd.nn.modules.head import _Plain
+    torch.manual_seed(cin * 3 + cout)
+    c1 = M.Conv(cin, 80, 1)
+    load_synth(c1, "ch1")
+    c1.fuse_bn()
+    c2 = nn.Conv2d(80, cout, 1)
+    with torch.no_grad():
+        c1.conv.weight.copy_(c1.conv.weight.half().float())
+        c2.weight.copy_((c2.weight * 3).half().float())
+    x = (torch.rand(2, cin, h, w) - 0.5).half()
+    c1f, c2f = to_dev(c1, torch.float32), c2.cuda().float()
+    mid = c1f(x.float().cuda())
+    want = _Plain(c2f).run(mid.half().float(), L.empty_nhwc(2, cout, h, w, torch.float32, "cuda")).float().cpu()  # mid rounded to f16 like the fused kernel
+    c1h, c2h = to_dev(c1, torch.float16), c2.cuda().half()
+    out = L.empty_nhwc(2, cout, h, w, torch.float16, "cuda")
+    got = _ops.conv_pw_chain(_Plain(c2h), x.cuda(), c1h.folded, L.ACT_SILU, lambda: fold_bn(c2h.weight, c2h.bias, None), L.ACT_NONE, out)
+    assert got is not None
+    torch.testing.assert_close(got.float().cpu(), want, rtol=3e-3, atol=3e-3 * float(want.abs().max()))
