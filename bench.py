@@ -128,7 +128,17 @@ def main():
             pass
     else:
         # stage 1 = network forward, stage 2 = NMS; NMS of batch i overlaps the forward of batch i+1 (both always run in full)
-        pipe = PipelinedRunner(lambda im: model(im)[0], lambda pred: ops.nms_device(pred, conf, iou, max_det=max_det)[:2], images)
+        # (the head's decode launch belongs to stage 2: the next batch's backbone starts right behind the towers)
+        head = model.model[-1]
+
+        def stage1(im):
+            head.defer_decode = True
+            try:
+                return model(im)[0]
+            finally:
+                head.defer_decode = False
+
+        pipe = PipelinedRunner(stage1, lambda levels: ops.nms_device(head.decode(levels), conf, iou, max_det=max_det)[:2], images)
         for j in range(2):
             pipe.static_input(j).copy_(images)  # both buffer sets hold the resident batch: no per-step copy
 
@@ -181,7 +191,7 @@ def main():
                                    f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
                        "global_batch": a.batch * world, "imgsz": a.imgsz,
-                       "pipeline": "single graph per batch" if a.no_pipeline else "forward(i+1) || NMS(i) on two HIP streams, 2 graphs per batch", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
+                       "pipeline": "single graph per batch" if a.no_pipeline else "backbone+neck+head towers(i+1) || head decode+NMS(i) on two HIP streams, 2 graphs per batch", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:
         from edge_yolo_amd import profiling

@@ -173,13 +173,28 @@ class Detect(nn.Module):
         if fork:
             for side in self._side:
                 cur.wait_stream(side)
+        if getattr(self, "defer_decode", False):
+            # two-stage pipelines (engine/predictor.py::PipelinedRunner) put the decode into the post-processing stage, next to the
+            # NMS: the next batch's backbone then starts as soon as the towers are done instead of behind the decode launch
+            return levels, x
+        self._decode(levels, pred)
+        return pred if self.export else (pred, x)
+
+    def _decode(self, levels, pred):
         # every level is decoded by ONE launch (reference: Detect._inference runs after all towers, head.py:84-90,117-148)
         if len(levels) <= 4:
             ops.head_decode_levels(levels, pred)
         else:
             for box, cls, st, q, off in levels:
                 ops.head_decode(box, cls, st, q, pred, off)
-        return pred if self.export else (pred, x)
+        return pred
+
+    def decode(self, levels):
+        """second half of forward() for callers that deferred it (`defer_decode`): levels -> pred (B, 4+nc, A) fp32."""
+        box0 = levels[0][0]
+        A = sum(lv[0].shape[2] * lv[0].shape[3] for lv in levels)
+        pred = torch.empty((box0.shape[0], 4 + self.nc, A), dtype=torch.float32, device=box0.device)
+        return self._decode(levels, pred)
 
     def bias_init(self):
         """reference head.py:150-161 (needs self.stride)."""
