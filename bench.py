@@ -127,20 +127,32 @@ def main():
         def drain():
             pass
     else:
-        # stage 1 = network forward, stage 2 = NMS; NMS of batch i overlaps the forward of batch i+1 (both always run in full)
-        # (the head's decode launch belongs to stage 2: the next batch's backbone starts right behind the towers)
-        head = model.model[-1]
-
-        def stage1(im):
-            head.defer_decode = True
-            try:
-                return model(im)[0]
-            finally:
-                head.defer_decode = False
-
-        pipe = PipelinedRunner(stage1, lambda levels: ops.nms_device(head.decode(levels), conf, iou, max_det=max_det)[:2], images)
-        for j in range(2):
-            pipe.static_input(j).copy_(images)  # both buffer sets hold the resident batch: no per-step copy
+        # software pipeline over consecutive batches: every stage is a captured hipGraph on its own stream; stage s of batch i overlaps
+        # stage s-1 of batch i+1 (every batch still runs every stage in full; the timed region ends with a drain of all stages)
+        if "EY_HEAD_STREAMS" not in os.environ:  # the head runs as a pipeline stage of its own: no fork inside it (measured: 1.93 -> 1.89 ms)
+            import edge_yolo_amd.nn.modules.head as _hm
+            _hm._HEAD_STREAMS = False
+        nlayers = len(model.model)
+        # 4 stages = 4 HIP streams = the 4 hardware queues (measured on MI355X: 2 stages 1.90, 3 stages 1.82, 4 stages 1.55 ms/step;
+        # 5+ stages alias queues and collapse to 2.35; GPU_MAX_HW_QUEUES 6/8 are worse).  Cuts at ~39 % / ~70 % of the layer list and
+        # before the head: for the 24-layer YAMLs 9, 16, 23 (backbone | backbone tail + upper neck | lower neck | head + decode + NMS).
+        dflt = sorted({max(1, round(0.39 * (nlayers - 1))), max(2, round(0.70 * (nlayers - 1))), nlayers - 1})
+        cuts = [int(v) for v in os.environ["EY_PIPE_CUTS"].split(",") if v] if os.environ.get("EY_PIPE_CUTS") else dflt  # layer indices where a new stage starts
+        post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
+        bounds = [0] + cuts + [nlayers]
+        stages = []
+        for k in range(len(bounds) - 1):
+            lo, hi = bounds[k], bounds[k + 1]
+            if k == 0:
+                stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi))
+            else:
+                stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi))
+        # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
+        last = stages.pop()
+        stages.append(lambda stt, last=last: post(last(stt)))
+        pipe = PipelinedRunner(*stages, images)
+        for j in range(pipe.n):
+            pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
 
         def step():
             j = pipe.submit()
@@ -191,7 +203,7 @@ def main():
                                    f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
                        "global_batch": a.batch * world, "imgsz": a.imgsz,
-                       "pipeline": "single graph per batch" if a.no_pipeline else "backbone+neck+head towers(i+1) || head decode+NMS(i) on two HIP streams, 2 graphs per batch", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
+                       "pipeline": "single graph per batch" if a.no_pipeline else f"{len(cuts) + 1}-stage software pipeline over consecutive batches (layer cuts {cuts}; last stage = head + decode + NMS), one hipGraph and one HIP stream per stage", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:
         from edge_yolo_amd import profiling

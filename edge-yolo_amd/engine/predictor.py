@@ -72,60 +72,66 @@ class GraphRunner:
 
 
 class PipelinedRunner:
-    """Two-stage software pipeline over consecutive batches: stage 1 (network forward -> pred) of batch i+1 runs on one HIP
-    stream while stage 2 (NMS: one latency-bound workgroup per image, ~1/8 of the CUs) of batch i runs on another.  Each
-    stage is a captured hipGraph; two buffer sets alternate, so nothing is copied between the stages.  Every batch still
-    goes through both stages in full — only their placement in time overlaps (throughput mode; one batch of extra latency).
+    """Software pipeline over consecutive batches: stage s of batch i runs on its own HIP stream while stage s-1 of batch i+1 and
+    stage s+1 of batch i-1 run on theirs.  Most kernels of this network at batch 32 are latency-bound (small feature maps, a few
+    hundred workgroups), so independent work from neighbouring batches fills the chip.  Each stage is a captured hipGraph; as many
+    buffer sets as stages alternate, so nothing is copied between the stages.  Every batch still goes through every stage in full --
+    only their placement in time overlaps (throughput mode; stages-1 batches of extra latency).
+
+    PipelinedRunner(f1, f2, ..., example): stage functions chained (stage k gets stage k-1's return value), example = input batch.
     """
 
-    def __init__(self, forward_fn, post_fn, example, warmup=2):
+    def __init__(self, *args, warmup=2):
+        *stages, example = args
         dev = example.device
-        self.dev = dev
-        self.sf, self.sp = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        self.dev, self.n = dev, len(stages)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in stages]
+        self.sf, self.sp = self.streams[0], self.streams[-1]
         self.sets = []
         cur = torch.cuda.current_stream(dev)
-        for _ in range(2):
+        for _ in range(self.n):
             static_in = example.clone()
             self.sf.wait_stream(cur)
             with torch.cuda.stream(self.sf):
                 for _ in range(warmup):
-                    mid = forward_fn(static_in)
-                    out = post_fn(mid)
+                    v = static_in
+                    for f in stages:
+                        v = f(v)
             cur.wait_stream(self.sf)
             torch.cuda.synchronize(dev)
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                mid = forward_fn(static_in)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                out = post_fn(mid)
-            self.sets.append(dict(x=static_in, g1=g1, g2=g2, out=out, fwd_done=torch.cuda.Event(), post_done=torch.cuda.Event()))
+            graphs, v = [], static_in
+            for f in stages:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    v = f(v)
+                graphs.append(g)
+            self.sets.append(dict(x=static_in, graphs=graphs, out=v, done=[torch.cuda.Event() for _ in stages]))
         self.i = 0
         for st in self.sets:  # events start in the signalled state
-            st["fwd_done"].record(cur)
-            st["post_done"].record(cur)
+            for e in st["done"]:
+                e.record(cur)
+        for st in self.sets:
+            st["post_done"] = st["done"][-1]
 
     def static_input(self, j=None):
-        return self.sets[self.i & 1 if j is None else j]["x"]
+        return self.sets[self.i % self.n if j is None else j]["x"]
 
     def submit(self, x=None):
         """Enqueue one batch (x=None: the batch already sits in static_input()).  Returns the buffer-set index; its outputs
         are valid after `wait(j)` / a device synchronise."""
-        j = self.i & 1
+        j = self.i % self.n
         self.i += 1
         st = self.sets[j]
         cur = torch.cuda.current_stream(self.dev)
-        self.sf.wait_stream(cur)
-        with torch.cuda.stream(self.sf):
-            self.sf.wait_event(st["post_done"])  # NMS of the batch that used this buffer set two submits ago
-            if x is not None and x.data_ptr() != st["x"].data_ptr():
-                st["x"].copy_(x, non_blocking=True)
-            st["g1"].replay()
-            st["fwd_done"].record(self.sf)
-        with torch.cuda.stream(self.sp):
-            self.sp.wait_event(st["fwd_done"])
-            st["g2"].replay()
-            st["post_done"].record(self.sp)
+        self.streams[0].wait_stream(cur)
+        for s, (stream, g) in enumerate(zip(self.streams, st["graphs"])):
+            with torch.cuda.stream(stream):
+                # stage 0 waits for the LAST stage of the batch that used this buffer set n submits ago; stage s for stage s-1 of this batch
+                stream.wait_event(st["done"][-1] if s == 0 else st["done"][s - 1])
+                if s == 0 and x is not None and x.data_ptr() != st["x"].data_ptr():
+                    st["x"].copy_(x, non_blocking=True)
+                g.replay()
+                st["done"][s].record(stream)
         return j
 
     def outputs(self, j):
@@ -133,8 +139,8 @@ class PipelinedRunner:
 
     def wait(self, j=None):
         cur = torch.cuda.current_stream(self.dev)
-        for k in ([j] if j is not None else [0, 1]):
-            cur.wait_event(self.sets[k]["post_done"])
+        for k in ([j] if j is not None else range(self.n)):
+            cur.wait_event(self.sets[k]["done"][-1])
 
 
 class DetectionPredictor:

@@ -153,13 +153,16 @@ class Detect(nn.Module):
         smap = _HEAD_MAP if (_HEAD_MAP and len(_HEAD_MAP) == 2 * len(xs)) else [0, 0] + [1] * (2 * len(xs) - 2)
         if fork and (getattr(self, "_side", None) is None or self._side_dev != dev or len(self._side) != max(smap)):
             self._side, self._side_dev = [torch.cuda.Stream(device=dev) for _ in range(max(smap))], dev
+        # every buffer a side stream WRITES is allocated before the fork: a block handed out later on the caller's stream could be one
+        # that kernels still queued there are using (the caching allocator orders reuse per stream only)
+        raws = [L.empty_nhwc(B, (self.no + 7) // 8 * 8, t.shape[2], t.shape[3], dt, dev)[:, :self.no] for t in xs]  # pixel stride kept 16-byte aligned for any nc
         if fork:
             for side in self._side:
                 side.wait_stream(cur)
         task = 0
         for i, t in enumerate(xs):
             H, W = t.shape[2:]
-            raw = L.empty_nhwc(B, (self.no + 7) // 8 * 8, H, W, dt, dev)[:, :self.no]  # pixel stride kept 16-byte aligned for any nc
+            raw = raws[i]
             for tower in (self._box_tower, self._cls_tower):
                 if fork and smap[task] > 0:
                     with torch.cuda.stream(self._side[smap[task] - 1]):

@@ -147,6 +147,29 @@ class BaseModel(nn.Module):
             y.append(x if m.i in self.save else None)
         return x
 
+    def forward_features(self, x):
+        """_predict_once without the last (head) module: returns the head's input list (for callers that pipeline the head apart)."""
+        y = []
+        for m in self.model[:-1]:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        h = self.model[-1]
+        return [x if j == -1 else y[j] for j in h.f] if not isinstance(h.f, int) else (x if h.f == -1 else y[h.f])
+
+    def forward_layers(self, state, lo, hi):
+        """Layers [lo, hi) of _predict_once on `state` = (x, saved outputs so far) -> new state: lets a caller cut the graph into
+        pipeline stages (each stage a captured hipGraph on its own stream)."""
+        x, y = state
+        y = list(y)
+        for m in self.model[lo:hi]:
+            if m.f != -1:
+                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+            x = m(x)
+            y.append(x if m.i in self.save else None)
+        return x, y
+
     def fuse(self, verbose=False):
         """Fold every Conv/DWConv BatchNorm into its conv parameters (reference tasks.py:214-242).  DSConv keeps its
         BatchNorm as a module, as in the reference; it is folded when the HIP weights are packed."""
