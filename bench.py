@@ -113,7 +113,9 @@ def main():
         return boxes, count
 
     # pipelined mode: the gather rides on the post-processing stream (no stream of its own)
-    gather = eydist.BoxGatherer(world, a.batch, max_det, dev, own_stream=a.no_pipeline) if (world > 1 or force_gather) else None
+    # ... and exchanges the rows of EY_GATHER_EVERY (8) consecutive batches with one all_gather (see BoxGatherer)
+    gather = (eydist.BoxGatherer(world, a.batch, max_det, dev, own_stream=a.no_pipeline, every=int(os.environ.get("EY_GATHER_EVERY", "8")))
+              if (world > 1 or force_gather) else None)
     if a.no_pipeline:
         runner = GraphRunner(device_step)
         images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
@@ -133,10 +135,12 @@ def main():
             import edge_yolo_amd.nn.modules.head as _hm
             _hm._HEAD_STREAMS = False
         nlayers = len(model.model)
-        # 4 stages = 4 HIP streams = the 4 hardware queues (measured on MI355X: 2 stages 1.90, 3 stages 1.82, 4 stages 1.55 ms/step;
-        # 5+ stages alias queues and collapse to 2.35; GPU_MAX_HW_QUEUES 6/8 are worse).  Cuts at ~39 % / ~70 % of the layer list and
-        # before the head: for the 24-layer YAMLs 9, 16, 23 (backbone | backbone tail + upper neck | lower neck | head + decode + NMS).
-        dflt = sorted({max(1, round(0.39 * (nlayers - 1))), max(2, round(0.70 * (nlayers - 1))), nlayers - 1})
+        # Active streams = hardware queues (4 on this stack; GPU_MAX_HW_QUEUES 6/8 are worse).  Measured on MI355X, ms/step: 2 stages 1.90,
+        # 3 stages 1.82-1.92, 4 stages 1.52 (cuts 9,20,23), 5+ stages alias queues and collapse to 2.35.  With a process group (N > 1) the
+        # collective backend's internal stream is the fourth one: 3 stages (cuts 9,23) 1.51, 4 stages 2.34.  Cuts sit at ~39 % / ~87 % of the
+        # layer list and before the head (24-layer YAMLs: backbone | backbone tail + neck | last neck block | head + decode + NMS).
+        c1, c2 = max(1, round(0.39 * (nlayers - 1))), max(2, round(0.87 * (nlayers - 1)))
+        dflt = sorted({c1, nlayers - 1}) if (world > 1 or force_gather) else sorted({c1, c2, nlayers - 1})
         cuts = [int(v) for v in os.environ["EY_PIPE_CUTS"].split(",") if v] if os.environ.get("EY_PIPE_CUTS") else dflt  # layer indices where a new stage starts
         post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
         bounds = [0] + cuts + [nlayers]
@@ -169,6 +173,8 @@ def main():
         step()
     drain()
     if gather is not None:
+        with torch.cuda.stream(pipe.sp if not a.no_pipeline else torch.cuda.current_stream()):
+            gather.flush()
         gather.wait()
     torch.cuda.synchronize()
     if world > 1:
@@ -178,7 +184,9 @@ def main():
     for _ in range(a.steps):
         boxes, count = step()
     drain()
-    if gather is not None:
+    if gather is not None:  # the last (possibly partial) block of rows is exchanged inside the timed region
+        with torch.cuda.stream(pipe.sp if not a.no_pipeline else torch.cuda.current_stream()):
+            gather.flush()
         gather.wait()
     torch.cuda.synchronize()
     if world > 1:
@@ -218,7 +226,7 @@ def main():
         print(json.dumps(out), flush=True)
     if gather is not None and rank == 0:
         rows = gather.results()
-        assert len(rows) == a.batch * world and all(r.shape[1] == 6 for r in rows)
+        assert len(rows) % (a.batch * world) == 0 and len(rows) > 0 and all(r.shape[1] == 6 for r in rows)
     if world > 1 or force_gather:
         dist.destroy_process_group()
 
