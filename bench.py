@@ -152,8 +152,11 @@ def main():
             else:
                 stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi))
         # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
-        last = stages.pop()
-        stages.append(lambda stt, last=last: post(last(stt)))
+        if os.environ.get("EY_PIPE_NMS_STAGE") == "1":  # experiment: decode + NMS as a stage of their own
+            stages.append(post)
+        else:
+            last = stages.pop()
+            stages.append(lambda stt, last=last: post(last(stt)))
         pipe = PipelinedRunner(*stages, images)
         for j in range(pipe.n):
             pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
