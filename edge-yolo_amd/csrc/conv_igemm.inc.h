@@ -1354,6 +1354,7 @@ struct EyTune {
   long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
   long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 128); // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
+  long grid_div = ey_env("EY_GRID_DIV", 1);           // persistent kernels: launch 1/grid_div of the resident slots (co-running pipeline stages share the chip)
   long c3r = ey_env("EY_C3R", 1);                     // register-stationary 3x3 kernel for Cin == 16 (0 = off)
   long tile_minwg = ey_env("EY_TILE_MINWG", 400);     // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
   long tile_flat = ey_env("EY_TILE_FLAT", 1);         // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)
@@ -1411,6 +1412,7 @@ static bool ws_launch(ConvP p, int ngroup, hipStream_t st) {
   // so a small layer still spreads over all CUs
   long cap = (long)256 * wg_per_cu / ((long)ntiles_n * ngroup);
   if (cap < 1) cap = 1;
+  cap = cap / tune().grid_div > 0 ? cap / tune().grid_div : 1;
   long gx = p.ntile < cap ? p.ntile : cap;
   if (tune().tiles_per_wave > 0) {
     long want = (p.ntile + 8 * tune().tiles_per_wave - 1) / (8 * tune().tiles_per_wave);
@@ -1586,7 +1588,7 @@ static int c3r_launch(const ConvP& p, int ngroup, hipStream_t st) {
   }
   const long ntile = (long)p.B * p.Ho * ((p.Wo + 15) / 16);
   if (ntile >= (1L << 31)) return 0;
-  long gx = (long)256 * occ / ngroup;
+  long gx = (long)256 * occ / ngroup / tune().grid_div;
   if (gx > (ntile + 3) / 4) gx = (ntile + 3) / 4;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL((conv3r_kernel<NT, S>), dim3((unsigned)gx, 1, (unsigned)ngroup), dim3(256), 0, st, p);
@@ -1715,7 +1717,7 @@ static int pwr_launch2(const ConvP& p, hipStream_t st) {
     occ = n > 4 ? 4 : n;
   }
   const unsigned ny = (unsigned)(conv_cout_pad(p.Cout) / (16 * NT));
-  long gx = (long)256 * occ / ny;
+  long gx = (long)256 * occ / ny / tune().grid_div;
   const long need = (p.ntile + 3) / 4;
   if (gx > need) gx = need;
   if (gx < 1) gx = 1;
@@ -1949,7 +1951,7 @@ static int pw2_launch(const ConvP& p, const ChainP& q, hipStream_t st) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)conv_pw2_kernel<NT1, KS1, NT2>, 256, 0) != hipSuccess || n < 1) n = 1;
     occ = n > 4 ? 4 : n;
   }
-  long gx = 256L * occ;
+  long gx = 256L * occ / tune().grid_div;
   if (gx > (p.ntile + 3) / 4) gx = (p.ntile + 3) / 4;
   if (gx < 1) gx = 1;
   hipLaunchKernelGGL((conv_pw2_kernel<NT1, KS1, NT2>), dim3((unsigned)gx), dim3(256), 0, st, p, q);
