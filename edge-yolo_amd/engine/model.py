@@ -105,6 +105,56 @@ class Model(torch.nn.Module):
 
     __call__ = predict
 
+    def predict_batches(self, batches, stages=4, **kwargs):
+        """Throughput form of predict(): a generator over an iterable of BCHW float tensors in [0,1] (all of one shape) that yields one
+        list of Results per batch, in order.  The layer list is cut into `stages` pipeline stages (engine/predictor.py::PipelinedRunner:
+        one hipGraph and one HIP stream per stage; batch i's head/NMS run beside batch i+1's neck and batch i+2's backbone), so the
+        results of a batch arrive `stages - 1` submissions later.  Same kwargs as predict() (conf, iou, max_det, half, agnostic_nms,
+        classes, device).  The reference has no counterpart (its stream=True generator still runs one batch at a time)."""
+        from .predictor import PipelinedRunner
+        from ..utils import ops
+        args = {"conf": 0.25, "iou": 0.7, "max_det": 300, "half": False, "agnostic_nms": False, "classes": None, "device": None}
+        unknown = set(kwargs) - set(args) - {"imgsz", "verbose"}
+        if unknown:
+            raise TypeError(f"predict_batches() got unsupported arguments {sorted(unknown)}")
+        args.update({k: v for k, v in kwargs.items() if k in args})
+        pipe, post, pending, nset = None, None, [], 0
+        for x in batches:
+            if pipe is None:
+                device = self._select_device(args["device"] if args["device"] is not None else (x.device if x.is_cuda else None))
+                m = self.model.to(device)
+                m.fuse()
+                m = (m.half() if args["half"] else m.float()).eval()
+                post = DetectionPredictor(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
+                                          agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=False)
+                n = len(m.model)
+                stages = max(2, min(int(stages), n))
+                cuts = sorted({max(1, round(0.39 * (n - 1))), max(2, round(0.87 * (n - 1))), n - 1})[-(stages - 1):]
+                bounds = [0] + cuts + [n]
+                fns = [(lambda st, lo=lo, hi=hi: m.forward_layers(st if lo else (st, []), lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+                last = fns.pop()
+                fns.append(lambda st, last=last: ops.nms_device(last(st)[0][0], args["conf"], args["iou"], args["classes"], args["agnostic_nms"], args["max_det"])[:2])
+                import edge_yolo_amd.nn.modules.head as _hm
+                fork, _hm._HEAD_STREAMS = _hm._HEAD_STREAMS, False  # the head is a pipeline stage of its own: no fork inside it while capturing
+                try:
+                    pipe = PipelinedRunner(*fns, post.preprocess(x))
+                finally:
+                    _hm._HEAD_STREAMS = fork
+                nset = pipe.n
+            im = post.preprocess(x)
+            while pending and (len(pending) >= nset or pending[0][0] == pipe.i % nset):  # the buffer set about to be reused must be read first
+                yield self._finish(pipe, post, *pending.pop(0))
+            pending.append((pipe.submit(im), im))
+        while pending:
+            yield self._finish(pipe, post, *pending.pop(0))
+
+    @staticmethod
+    def _finish(pipe, post, j, im):
+        pipe.wait(j)
+        boxes, count = pipe.outputs(j)
+        post._orig = None
+        return post.postprocess(boxes, count, im, None)
+
 
 class YOLO(Model):
     """YOLO detect model (reference models/yolo/model.py:11-59)."""

@@ -223,3 +223,17 @@ def test_multi_stage_pipeline_matches_direct_execution():
         assert torch.equal(c, wc)
         for i in range(2):
             torch.testing.assert_close(b[i, : int(wc[i])], wb[i, : int(wc[i])], rtol=0, atol=0, equal_nan=True, msg=lambda s_: f"in-flight batch {k} image {i}: {s_}")
+
+
+def test_predict_batches_matches_predict():
+    """The throughput generator (4-stage batch pipeline) returns, in order, the same boxes as one predict() call per batch."""
+    import edge_yolo_amd
+    torch.manual_seed(11)
+    model = edge_yolo_amd.YOLO("yolo11n-test.yaml")
+    xs = [torch.rand(2, 3, 128, 160) for _ in range(6)]
+    outs = list(model.predict_batches(xs, conf=0.25, half=True))
+    assert len(outs) == len(xs) and all(len(o) == 2 for o in outs)
+    for x, res in zip(xs, outs):
+        ref = model.predict(x, conf=0.25, half=True)
+        for a, b in zip(res, ref):
+            assert torch.equal(a.boxes.data.cpu(), b.boxes.data.cpu())
