@@ -1352,7 +1352,7 @@ struct EyTune {
   long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
   long ws_k3_minnt = ey_env("EY_WS_K3_MINNT", 0);     // 3x3: use the K-chunked kernel when the weight-stationary tile would cover fewer than this many 16-channel blocks (and not all of Cout)
   long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
-  long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 128); // tile kernel for stride 2 only from this many input channels ...
+  long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 64);  // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
   long grid_div = ey_env("EY_GRID_DIV", 1);           // persistent kernels: launch 1/grid_div of the resident slots (co-running pipeline stages share the chip)
   long c3r = ey_env("EY_C3R", 1);                     // register-stationary 3x3 kernel for Cin == 16 (0 = off)
