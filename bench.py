@@ -2,18 +2,24 @@
 """Headline benchmark: images/s of the EdgeLine-YOLO detection forward path (stem -> backbone -> DWT neck ->
 GFLv2 head decode -> batched NMS) at 640x640, fp16 storage, synthetic images already resident in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model yolo11n-test.yaml] [--batch 32] [--imgsz 640]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model yolo11n-test.yaml] [--batch 32] [--imgsz 640] [--nc 80]
 
 N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; one process per GPU,
 images sharded across ranks (weak scaling: 32 images per GPU), one RCCL all_gather of the padded (B,300,6) result
-rows + counts per step on a side stream.  Rank 0 prints ONE JSON line.
+rows + counts per `--gather-every` steps.  Rank 0 prints ONE JSON line.
 
-A "step" = one batch through the whole device path, replayed from a captured hipGraph: nothing is skipped (NMS and,
-for N>1, the gather are inside the timed region).  `roofline` = the dominant kernel of the step measured live with HIP
-events on the launch stream in an instrumented eager pass of the same steps; `cpu_baseline` = the CPU oracle
-(oracle/, a port of the reference's torch-CPU path, test infrastructure) timed on this box's host cores, rank 0, N=1.
+A "step" = one batch through the whole device path, replayed from captured hipGraphs: nothing is skipped (NMS and,
+for N>1, the gather are inside the timed region).  `roofline` = per-kernel HIP-event timing of an instrumented eager pass of the
+same step (dominant kernel at the top level, every kernel in `roofline.table`, whole-step fractions in `roofline.step`);
+`cpu_baseline` = the CPU oracle (oracle/, a port of the reference's torch-CPU path, test infrastructure) timed on this box's host
+cores, rank 0, N=1, with its calibration against the true reference (profiles/*_cpu_calibration.json, measured where both run);
+`predict_batches` = images/s through the public API (`YOLO.predict_batches`: pinned host tensors in, `Results` out).
+
+All behaviour is selected by the flags below: this file and the library read no EY_* environment variables.
 """
 import argparse
+import contextlib
+import glob
 import json
 import os
 import sys
@@ -29,27 +35,35 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achiev
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="yolo11n-test.yaml")
+    ap.add_argument("--nc", type=int, default=80, help="number of classes (GC10-DET: 10)")
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--dtype", default="f16", choices=["f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=16)
-    ap.add_argument("--no-pipeline", action="store_true", help="one graph per batch, no overlap of NMS(i) with forward(i+1)")
-    return ap.parse_args()
+    ap.add_argument("--no-api", action="store_true", help="skip the YOLO.predict_batches (host tensors in, Results out) measurement")
+    ap.add_argument("--cpu-images", type=int, default=64)
+    ap.add_argument("--no-pipeline", action="store_true", help="one graph per batch, no overlap between consecutive batches")
+    ap.add_argument("--stages", default="auto", help="pipeline stages: 2, 3, 4 or 'auto' (times 3 and 4 at start-up and keeps the faster)")
+    ap.add_argument("--cuts", default="", help="explicit layer indices where a new pipeline stage starts, e.g. 9,20,23 (overrides --stages)")
+    ap.add_argument("--nms-stage", action="store_true", help="experiment: decode + NMS as a pipeline stage of their own")
+    ap.add_argument("--gather-every", type=int, default=8, help="N>1: exchange the result rows of this many steps with one all_gather")
+    ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path on a single GPU (world_size 1)")
+    ap.add_argument("--roofline-csv", default="", help="also write roofline.table as CSV (for profiles/)")
+    return ap.parse_args(argv)
 
 
-def build_model(name, dtype, device, seed=0):
+def build_model(name, dtype, device, seed=0, nc=None):
     import edge_yolo_amd  # noqa: F401
     from edge_yolo_amd.nn.tasks import DetectionModel
-    from oracle import synth  # synthetic weight generator only (name-keyed, shared with the tests)
-    m = DetectionModel(name)
+    import synthdata as synth  # name-keyed synthetic weights (neutral module shared with the tests; not part of the oracle)
+    m = DetectionModel(name, nc=nc)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
     m.load_state_dict(sd)
     m = m.to(device).fuse()
@@ -57,26 +71,121 @@ def build_model(name, dtype, device, seed=0):
     return m.eval(), sd
 
 
-def cpu_baseline(name, sd, imgsz, n_images, conf, iou):
+def cpu_baseline(name, sd, imgsz, n_images, conf, iou, nc=None):
     """The CPU port of the reference path (oracle/) on this box's host cores: forward + NMS, fp32."""
     from oracle import model as om, nms as onms
     ncpu = os.cpu_count() or 1
     threads = max(1, min(8, ncpu - 1))  # the reference's select_device rule (utils/torch_utils.py:225-226)
     torch.set_num_threads(threads)
-    o = om.OracleModel(os.path.join(ROOT, "edge-yolo_amd", "cfg", "models", "11", name), {k: v.float() for k, v in sd.items()})
+    o = om.OracleModel(os.path.join(ROOT, "edge-yolo_amd", "cfg", "models", "11", name), {k: v.float() for k, v in sd.items()}, nc=nc)
     g = torch.Generator().manual_seed(0)
     bs = min(8, n_images)
     x = torch.rand(bs, 3, imgsz, imgsz, generator=g)
     o(x[:1])  # warm-up
     t0 = time.perf_counter()
-    done = 0
+    done, t_fwd = 0, 0.0
     while done < n_images:
+        t1 = time.perf_counter()
         y, _ = o(x)
+        t_fwd += time.perf_counter() - t1
         onms.non_max_suppression(y.numpy(), conf, iou)
         done += bs
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{done} images {imgsz}x{imgsz} fp32, batch {bs}, forward+NMS, oracle/ (torch-CPU port of the reference path), {threads} threads"}
+    out = {"value": round(done / dt, 3), "unit": "images/s", "cores": threads, "kind": "port", "forward_only_images_s": round(done / t_fwd, 3),
+           "sample": f"{done} images {imgsz}x{imgsz} fp32, batch {bs}, forward+NMS, oracle/ (torch-CPU port of the reference path), {threads} threads"}
+    cal = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_cpu_calibration.json")))
+    if cal:  # port vs TRUE reference, forward only, measured in the build container (tools/cpu_calibration.py): the reference cannot travel here
+        try:
+            c = json.load(open(cal[-1]))
+            out["calibration"] = {"port_over_reference": c["port_over_reference"], "reference_img_s": c["reference_img_s"], "port_img_s": c["port_img_s"],
+                                  "what": c["what"], "where": c["host"], "images": c["images"], "source": "profiles/" + os.path.basename(cal[-1])}
+        except (OSError, ValueError, KeyError):
+            pass
+    return out
+
+
+def pipeline_cuts(nlayers, nstages):
+    """Layer indices where a new pipeline stage starts.  24-layer YAMLs: 4 stages = backbone | backbone tail + neck | last neck block |
+    head + decode + NMS (cuts at ~39 % / ~87 % of the layer list and before the head); fewer stages drop the middle cuts."""
+    c1, c2 = max(1, round(0.39 * (nlayers - 1))), max(2, round(0.87 * (nlayers - 1)))
+    return {2: [nlayers - 1], 3: sorted({c1, nlayers - 1}), 4: sorted({c1, c2, nlayers - 1})}[nstages]
+
+
+def timed_steps(step, drain, gather, steps, warmup, post_ctx, sync, barrier, reduce_max, on_block=None):
+    """The bench's control flow: `warmup` untimed steps, then EXACTLY `steps` timed ones bracketed by barrier + device sync on both
+    sides; the gather of every step's rows (and the flush of the last, possibly partial, block) is inside the timed region.  Shared
+    by the real run and by the world-size-2 gloo rehearsal in tests/ (stub step, CPU tensors).  Returns (seconds, last step result)."""
+    def one():
+        res = step()
+        if gather is not None:
+            with post_ctx():  # the gather follows this batch's NMS on the post-processing stream
+                k = gather(*res)
+            if k is not None and on_block is not None:
+                on_block(k)
+        return res
+
+    def finish():
+        drain()
+        if gather is not None:
+            with post_ctx():
+                k = gather.flush()
+            gather.wait()
+            if k is not None and on_block is not None:
+                on_block(k)
+
+    for _ in range(warmup):
+        one()
+    finish()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(steps):
+        res = one()
+    finish()
+    sync()
+    barrier()
+    sync()
+    return reduce_max(time.perf_counter() - t0), res
+
+
+def choose_variant(variants, trial, reduce_max):
+    """Start-up auto-tune: `variants` = {name: builder}; every rank builds and times each one with `trial(obj) -> seconds`; the times
+    are max-reduced over the ranks, so all ranks pick the same winner.  Returns (name, object, {name: seconds})."""
+    best, times, objs = None, {}, {}
+    for name, make in variants.items():
+        objs[name] = make()
+        times[name] = reduce_max(trial(objs[name]))
+        if best is None or times[name] < times[best]:
+            best = name
+    for name in list(objs):
+        if name != best:
+            del objs[name]
+    return best, objs[best], times
+
+
+def api_throughput(name, sd, nc, batch, imgsz, half, steps, warmup, conf, iou, max_det, device):
+    """images/s through the public API: YOLO.predict_batches with pinned HOST tensors in and Results out (PCIe upload included)."""
+    import edge_yolo_amd
+    y = edge_yolo_amd.YOLO(name, nc=nc)
+    y.model.load_state_dict(sd)
+    dt = torch.float16 if half else torch.float32
+    x = torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(0)).to(dt).pin_memory()
+    total = warmup + steps
+    t0, n, ndet = None, 0, 0
+    for res in y.predict_batches((x for _ in range(total)), half=half, conf=conf, iou=iou, max_det=max_det, device=device):
+        n += 1
+        if n == warmup:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        elif n > warmup:
+            ndet += sum(len(r) for r in res)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    return {"value": round(steps * batch / sec, 2), "unit": "images/s", "ms_per_batch": round(sec / steps * 1e3, 4), "batches": steps,
+            "what": f"YOLO.predict_batches(half={half}): pinned host {str(dt).split('.')[-1]} tensors ({x.numel() * x.element_size() / 1e6:.1f} MB per batch over PCIe) in, "
+                    f"Results (device boxes + host counts) out; mean detections/img {ndet / max(1, steps * batch):.0f}"}
 
 
 def main():
@@ -84,13 +193,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if a.gpus != world and world == 1 and a.gpus > 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    force_gather = os.environ.get("EY_FORCE_GATHER") == "1"  # exercise the RCCL gather path on a single GPU (world_size 1)
-    if world > 1 or force_gather:
+    use_gather = world > 1 or a.force_gather
+    if use_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -102,7 +210,7 @@ def main():
     from edge_yolo_amd.engine.predictor import GraphRunner, PipelinedRunner
     from edge_yolo_amd.utils import ops
     from edge_yolo_amd import dist as eydist
-    model, sd = build_model(a.model, dtype, dev)
+    model, sd = build_model(a.model, dtype, dev, nc=a.nc)
 
     g = torch.Generator(device=dev).manual_seed(rank)
     images = torch.rand(a.batch, 3, a.imgsz, a.imgsz, generator=g, device=dev).to(dtype)  # resident in HBM before timing
@@ -112,125 +220,113 @@ def main():
         boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
         return boxes, count
 
-    # pipelined mode: the gather rides on the post-processing stream (no stream of its own)
-    # ... and exchanges the rows of EY_GATHER_EVERY (8) consecutive batches with one all_gather (see BoxGatherer)
-    gather = (eydist.BoxGatherer(world, a.batch, max_det, dev, own_stream=a.no_pipeline, every=int(os.environ.get("EY_GATHER_EVERY", "8")))
-              if (world > 1 or force_gather) else None)
+    def reduce_max(sec):
+        if world > 1:
+            t = torch.tensor([sec], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return sec
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # pipelined mode: the gather rides on the post-processing stream (no stream of its own) and exchanges the rows of
+    # --gather-every consecutive batches with one all_gather (see BoxGatherer)
+    gather = eydist.BoxGatherer(world, a.batch, max_det, dev, own_stream=a.no_pipeline, every=a.gather_every) if use_gather else None
+    chosen, trial_ms = None, None
     if a.no_pipeline:
         runner = GraphRunner(device_step)
         images = runner.static_input(images).copy_(images)  # the batch lives in the graph's input buffer: no per-step copy
-
-        def step():
-            boxes, count = runner(images)
-            if gather is not None:
-                gather(boxes, count)
-            return boxes, count
-
-        def drain():
-            pass
+        step, drain, post_ctx = (lambda: runner(images)), (lambda: None), contextlib.nullcontext
     else:
         # software pipeline over consecutive batches: every stage is a captured hipGraph on its own stream; stage s of batch i overlaps
         # stage s-1 of batch i+1 (every batch still runs every stage in full; the timed region ends with a drain of all stages)
-        if "EY_HEAD_STREAMS" not in os.environ:  # the head runs as a pipeline stage of its own: no fork inside it (measured: 1.93 -> 1.89 ms)
-            import edge_yolo_amd.nn.modules.head as _hm
-            _hm._HEAD_STREAMS = False
+        model.model[-1].head_streams = False  # the head runs as a pipeline stage of its own: no fork inside it (measured: 1.93 -> 1.89 ms)
         nlayers = len(model.model)
-        # Active streams = hardware queues (4 on this stack; GPU_MAX_HW_QUEUES 6/8 are worse).  Measured on MI355X, ms/step: 2 stages 1.90,
-        # 3 stages 1.82-1.92, 4 stages 1.52 (cuts 9,20,23), 5+ stages alias queues and collapse to 2.35.  With a process group (N > 1) the
-        # collective backend's internal stream is the fourth one: 3 stages (cuts 9,23) 1.51, 4 stages 2.34.  Cuts sit at ~39 % / ~87 % of the
-        # layer list and before the head (24-layer YAMLs: backbone | backbone tail + neck | last neck block | head + decode + NMS).
-        c1, c2 = max(1, round(0.39 * (nlayers - 1))), max(2, round(0.87 * (nlayers - 1)))
-        dflt = sorted({c1, nlayers - 1}) if (world > 1 or force_gather) else sorted({c1, c2, nlayers - 1})
-        cuts = [int(v) for v in os.environ["EY_PIPE_CUTS"].split(",") if v] if os.environ.get("EY_PIPE_CUTS") else dflt  # layer indices where a new stage starts
         post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
-        bounds = [0] + cuts + [nlayers]
-        stages = []
-        for k in range(len(bounds) - 1):
-            lo, hi = bounds[k], bounds[k + 1]
-            if k == 0:
-                stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi))
+
+        def make_pipe(cuts):
+            bounds = [0] + list(cuts) + [nlayers]
+            stages = []
+            for k in range(len(bounds) - 1):
+                lo, hi = bounds[k], bounds[k + 1]
+                if k == 0:
+                    stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi))
+                else:
+                    stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi))
+            # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
+            if a.nms_stage:
+                stages.append(post)
             else:
-                stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi))
-        # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
-        if os.environ.get("EY_PIPE_NMS_STAGE") == "1":  # experiment: decode + NMS as a stage of their own
-            stages.append(post)
+                last = stages.pop()
+                stages.append(lambda stt, last=last: post(last(stt)))
+            pipe = PipelinedRunner(*stages, images)
+            for j in range(pipe.n):
+                pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
+            pipe.cuts = list(cuts)
+            return pipe
+
+        def pipe_fns(pipe):
+            def step():
+                return pipe.outputs(pipe.submit())
+            return step, pipe.wait, (lambda: torch.cuda.stream(pipe.sp))
+
+        if a.cuts:
+            pipe = make_pipe([int(v) for v in a.cuts.split(",") if v])
+        elif a.stages != "auto":
+            pipe = make_pipe(pipeline_cuts(nlayers, int(a.stages)))
         else:
-            last = stages.pop()
-            stages.append(lambda stt, last=last: post(last(stt)))
-        pipe = PipelinedRunner(*stages, images)
-        for j in range(pipe.n):
-            pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
+            # Active streams = hardware queues (4 on this stack).  Which of 3 / 4 stages wins depends on what else is active (with a process
+            # group the collective backend's stream is one more): measured at start-up, same decision on every rank (max-reduced times).
+            def trial(p):
+                s, d, pc = pipe_fns(p)
+                return timed_steps(s, d, gather, 12, 4, pc, torch.cuda.synchronize, barrier, lambda v: v)[0]
+            chosen, pipe, tt = choose_variant({f"{n}": (lambda n=n: make_pipe(pipeline_cuts(nlayers, n))) for n in (3, 4)}, trial, reduce_max)
+            trial_ms = {k: round(v / 12 * 1e3, 4) for k, v in tt.items()}
+            torch.cuda.empty_cache()
+        step, drain, post_ctx = pipe_fns(pipe)
 
-        def step():
-            j = pipe.submit()
-            boxes, count = pipe.outputs(j)
-            if gather is not None:
-                with torch.cuda.stream(pipe.sp):  # the gather follows this batch's NMS on the post-processing stream
-                    gather(boxes, count)
-            return boxes, count
-
-        def drain():
-            pipe.wait()
-
-    for _ in range(a.warmup):
-        step()
-    drain()
-    if gather is not None:
-        with torch.cuda.stream(pipe.sp if not a.no_pipeline else torch.cuda.current_stream()):
-            gather.flush()
-        gather.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        boxes, count = step()
-    drain()
-    if gather is not None:  # the last (possibly partial) block of rows is exchanged inside the timed region
-        with torch.cuda.stream(pipe.sp if not a.no_pipeline else torch.cuda.current_stream()):
-            gather.flush()
-        gather.wait()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, (boxes, count) = timed_steps(step, drain, gather, a.steps, a.warmup, post_ctx, torch.cuda.synchronize, barrier, reduce_max)
 
     out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         total_images = a.batch * world * a.steps
+        pipe_desc = ("single graph per batch" if a.no_pipeline else
+                     f"{len(pipe.cuts) + 1}-stage software pipeline over consecutive batches (layer cuts {pipe.cuts}; last stage = head + decode + NMS), "
+                     "one hipGraph and one HIP stream per stage" + (f"; stage count auto-tuned at start-up, trial ms/step {trial_ms}" if trial_ms else ""))
         out = {
             "metric": f"images/sec @ {a.imgsz}x{a.imgsz} {'fp16' if a.dtype == 'f16' else 'fp32'} (EdgeLine-YOLO detection forward path: backbone + DWT neck + GFLv2 head decode + batched NMS)",
             "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": f"{a.model} (EdgeLine-YOLO scale n, nc=80) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
+            "config": {"workload": f"{a.model} (scale n, nc={a.nc}) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
                                    f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
-                       "global_batch": a.batch * world, "imgsz": a.imgsz,
-                       "pipeline": "single graph per batch" if a.no_pipeline else f"{len(cuts) + 1}-stage software pipeline over consecutive batches (layer cuts {cuts}; last stage = head + decode + NMS), one hipGraph and one HIP stream per stage", "sharding": f"images x{world}" + (", RCCL all_gather of boxes" if world > 1 else "")},
+                       "global_batch": a.batch * world, "imgsz": a.imgsz, "nc": a.nc, "pipeline": pipe_desc,
+                       "sharding": f"images x{world}" + (f", RCCL all_gather of boxes every {gather.every} steps" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:
         from edge_yolo_amd import profiling
         torch.cuda.synchronize()
-        out["roofline"] = profiling.dominant_kernel_roofline(lambda: device_step(images), steps=min(a.steps, 10), hbm_peak_gbs=HBM_PEAK_GBS,
-                                                             mfma_peak_tflops=MFMA_F16_PEAK_TFLOPS)
-    if world > 1:
-        dist.barrier()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+        model.model[-1].head_streams = False
+        out["roofline"] = profiling.step_roofline(lambda: device_step(images), steps=min(a.steps, 10), ms_per_step=out["ms_per_step"], hbm_peak_gbs=HBM_PEAK_GBS,
+                                                  mfma_peak_tflops=MFMA_F16_PEAK_TFLOPS, csv_path=a.roofline_csv or None)
+    barrier()
     if gather is not None and rank == 0:
         rows = gather.results()
         assert len(rows) % (a.batch * world) == 0 and len(rows) > 0 and all(r.shape[1] == 6 for r in rows)
-    if world > 1 or force_gather:
+    if rank == 0 and world == 1 and not a.no_api and not a.force_gather:
+        if not a.no_pipeline:
+            del pipe, step, drain
+        torch.cuda.empty_cache()
+        out["predict_batches"] = api_throughput(a.model, sd, a.nc, a.batch, a.imgsz, a.dtype == "f16", min(a.steps, 40), 8, conf, iou, max_det, dev)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou, nc=a.nc)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_gather:
         dist.destroy_process_group()
 
 

@@ -45,6 +45,8 @@ SIGNATURES = {
     "ey_last_error": (C.c_char_p, []),
     "ey_version": (_i, []),
     "ey_abi_sizeof": (_sz, [_i]),
+    "ey_tune_set": (_i, [C.c_char_p, C.c_long]),
+    "ey_tune_get": (C.c_long, [C.c_char_p]),
     "ey_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ey_conv_pack_weight": (_i, [_i, _i, _i, _i, _vp, _vp, _sz]),
     "ey_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
@@ -109,6 +111,9 @@ def check(code, what=""):
 
 
 def stream():
+    """HIP stream every launch goes to: torch's current stream of the CURRENT device.  Operands must live on that device --
+    `require_device` (called by every op on its first operand) raises otherwise; the engine entry points (BaseModel.predict,
+    DetectionPredictor, predict_batches, nms_device) enter `torch.cuda.device(<operand device>)` so `device='cuda:1'` works."""
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -124,6 +129,9 @@ def require_device(x, what):
     if not x.is_cuda:
         raise HipLibraryError(f"{what}: tensor is on '{x.device}'. edge-yolo_amd runs on MI355X only (no CPU fallback); "
                               "move the model/input to 'cuda'.")
+    if x.device.index != torch.cuda.current_device():
+        raise HipLibraryError(f"{what}: tensor is on '{x.device}' but the current device is cuda:{torch.cuda.current_device()}; kernels are launched on "
+                              "the current device's stream: wrap the call in `with torch.cuda.device(x.device):` (model.predict / YOLO.predict do)")
 
 
 def empty_nhwc(B, Cc, H, W, dtype, device):

@@ -7,6 +7,7 @@
 //   y[n][j]  = sum_i qs[n][i] * ctx[i][j]
 // One workgroup (8 waves) per (image, head); N is streamed, so N=1600 (1280^2 input) needs no more LDS than N=400.
 #include "common.h"
+#include "tune.h"
 #include <stdlib.h>
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -328,7 +329,7 @@ extern "C" int ey_linear_attention(int dtype, int B, int N, int C, int heads, co
   if (d > 64) return ey_set_error(EY_EUNSUPPORTED, "linear_attention: head_dim %d > 64", d);
   EY_CHECK(qkv_cstride >= 3 * C && y_cstride >= C, "linear_attention: cstride");
   dim3 grid(B * heads);
-  static const bool mfma_off = [] { const char* v = getenv("EY_LINATTN_MFMA"); return v && *v == '0'; }();
+  const bool mfma_off = !tune().linattn_mfma;
   if (dtype == EY_F16 && d == 64 && !mfma_off && (qkv_cstride * 2) % 16 == 0 && ey_aligned(qkv, 16) && C % 8 == 0 && (y_cstride * 2) % 8 == 0 && ey_aligned(y, 8)) {
     hipLaunchKernelGGL(linattn_mfma_kernel, grid, dim3(512), 0, (hipStream_t)stream, N, C, heads, (const f16*)qkv, qkv_cstride, (f16*)y, y_cstride);
     EY_LAUNCH_CHECK("ey_linear_attention(mfma)");
@@ -515,7 +516,7 @@ extern "C" int ey_softmax_attention(int dtype, int B, int N, int heads, int kd, 
   if (kd > 64) return ey_set_error(EY_EUNSUPPORTED, "softmax_attention: key_dim %d > 64", kd);
   EY_CHECK(qkv_cstride >= heads * (2 * kd + hd) && y_cstride >= heads * hd, "softmax_attention: cstride");
   const int es = dtype == EY_F16 ? 2 : 4;
-  static const bool sm_mfma_off = [] { const char* v = getenv("EY_SOFTATTN_MFMA"); return v && *v == '0'; }();
+  const bool sm_mfma_off = !tune().softattn_mfma;
   if (dtype == EY_F16 && kd == 32 && hd == 64 && N <= 32 * SM_MAXKS && !sm_mfma_off && (qkv_cstride * 2) % 16 == 0 && ey_aligned(qkv, 16) && (y_cstride * 2) % 8 == 0 &&
       ey_aligned(y, 8)) {
     const int nks = (N + 31) / 32;

@@ -1338,34 +1338,7 @@ static bool launch_conv(const ConvP& p, int ngroup, hipStream_t st) {
 
 // ---- tunables (defaults measured on MI355X; EY_* environment variables override them for sweeps)
 #include <stdlib.h>
-static long ey_env(const char* name, long dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atol(v) : dflt;
-}
-struct EyTune {
-  long tiles_per_wave = ey_env("EY_TPW", 0);          // ws: minimum tiles per wave before adding workgroups (0 = fill all slots)
-  long mt2_min_m = ey_env("EY_MT2_M", 300000);        // ws: 2 pixel blocks per wave from this many output pixels
-  long small_m = ey_env("EY_SMALL_M", 100000);        // small-M kernel below this many output pixels ...
-  long small_wbytes = ey_env("EY_SMALL_WMB", 48) << 20;  // ... while (#tiles x weight bytes) stays below this
-  long halo_min_c = ey_env("EY_HALO_MINC", 48);       // 3x3 halo kernel for Cin in [this, 64]
-  long ws_budget = ey_env("EY_WS_LDS_KB", 76) << 10;  // ws: preferred LDS per workgroup (2 workgroups per CU)
-  long ws_wg_cu = ey_env("EY_WS_WGCU", 2);            // ws: workgroups per CU when LDS allows
-  long ws_k3_minnt = ey_env("EY_WS_K3_MINNT", 0);     // 3x3: use the K-chunked kernel when the weight-stationary tile would cover fewer than this many 16-channel blocks (and not all of Cout)
-  long tile_wlds = ey_env("EY_TILE_WLDS", 1);         // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
-  long tile_s2_minc = ey_env("EY_TILE_S2_MINC", 64);  // tile kernel for stride 2 only from this many input channels ...
-  long tile_s2_minm = ey_env("EY_TILE_S2_MINM", 40000);  // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
-  long grid_div = ey_env("EY_GRID_DIV", 1);           // persistent kernels: launch 1/grid_div of the resident slots (co-running pipeline stages share the chip)
-  long c3r = ey_env("EY_C3R", 1);                     // register-stationary 3x3 kernel for Cin == 16 (0 = off)
-  long tile_minwg = ey_env("EY_TILE_MINWG", 400);     // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
-  long tile_flat = ey_env("EY_TILE_FLAT", 1);         // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)
-  long tile_mink = ey_env("EY_TILE_MINK", 0);         // 3x3 tile kernel for K = 9*Cin >= this (huge value = off)
-  long pwr_m = ey_env("EY_PWR_M", 110000);            // register-stationary pointwise kernel from this many output pixels (huge value = off)
-  long pwr_frags = ey_env("EY_PWR_FRAGS", 24);        // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
-  long pw_m = ey_env("EY_PW_M", 110000);              // lean pointwise kernel below this many output pixels (0 = off)
-  long pw_waves = ey_env("EY_PW_WAVES", 3072);        // pw: prefer the widest channel tile that still leaves this many waves
-  long pw_wbytes = ey_env("EY_PW_WMB", 64) << 20;     // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this
-};
-static const EyTune& tune() { static EyTune t; return t; }
+#include "tune.h"
 // kind*1000 + NT*10 + x of the kernel the last ey_conv2d launched (profiling labels); defined in the f16 translation unit
 #if EY_CONV_PART == 16
 thread_local int g_last_variant = 0;
@@ -1645,7 +1618,7 @@ static int small_pick_nt(int Cout, int es) {
 #define EY_SMALL_M 100000
 static bool small_ok(int Cout, int Kpad, int k, long M, int es) {
   if (k != 1 || M >= tune().small_m) return false;
-  return ((M + 15) / 16) * (long)conv_cout_pad(Cout) * Kpad * es <= tune().small_wbytes;
+  return ((M + 15) / 16) * (long)conv_cout_pad(Cout) * Kpad * es <= (tune().small_wmb << 20);
 }
 
 template <typename T>
@@ -1780,7 +1753,7 @@ template <typename T>
 static int dispatch_pw(ConvP p, int ngroup, hipStream_t st) {
   const long M = (long)p.B * p.Ho * p.Wo;
   if (p.k != 1 || p.stride != 1 || ngroup != 1 || M >= tune().pw_m) return 0;
-  if (((M + 15) / 16) * (long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) > tune().pw_wbytes) return 0;  // every wave re-reads its weight rows
+  if (((M + 15) / 16) * (long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) > (tune().pw_wmb << 20)) return 0;  // every wave re-reads its weight rows
   if ((long)conv_cout_pad(p.Cout) * p.Kpad * (long)sizeof(T) >= (1L << 31)) return 0;
   for (int s2 = 0; s2 < p.nsrc; ++s2) {
     const int up = p.srcUp[s2];
@@ -1805,7 +1778,7 @@ static int dispatch_pw(ConvP p, int ngroup, hipStream_t st) {
 // returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
 template <typename T>
 static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
-  int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), (size_t)tune().ws_budget);
+  int nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), (size_t)(tune().ws_lds_kb << 10));
   if (!nt) nt = ws_pick_nt(p.Cout, p.Kpad, sizeof(T), 156 * 1024);
   if (!nt) return 0;
   if (p.k == 3 && nt < tune().ws_k3_minnt && nt < conv_nt(p.Cout)) return 0;

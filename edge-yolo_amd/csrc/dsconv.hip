@@ -10,6 +10,7 @@
 //      same packed-weight layout and wide-store epilogue as the dense conv (bias, SiLU, residual).
 // The intermediate (B,C,H,W) tensor of the unfused form never touches HBM: x is read once, y written once.
 #include "common.h"
+#include "tune.h"
 
 static thread_local int g_ds_variant = 0;  // kernel the last ey_dsconv / ey_dsconv_tz launched: 1 LDS tile, 2 register strip, 3 Toeplitz MFMA
 struct DsP {
@@ -562,12 +563,11 @@ static int ds_strip_launch(const DsP& p, hipStream_t st) {
   if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_dsconv(strip): %s", hipGetErrorString(e_));
   return 1;
 }
-static long ds_env(const char* n, long d) { const char* v = getenv(n); return v && *v ? atol(v) : d; }
 template <int K, int NT, int KS>
 static int ds_strip_p(const DsP& p, hipStream_t st) {
   // measured on MI355X (tools/ds_bench.py): k=7 wants the long strip (49 taps: reuse of loaded vectors dominates), k=3/5 the
   // short ones (more waves; the per-wave instruction stream sets the time), 2-pixel strips once a 64-channel map has >= 40k pixels
-  static const long force = ds_env("EY_DS_P", 0);
+  const long force = tune().ds_p;
   const long px = (long)p.B * p.H * p.W;
   int P = K == 7 ? 4 : (p.Cin >= 64 && px >= 40000) ? 2 : 1;
   if (force) P = (int)force;
@@ -583,8 +583,7 @@ static int ds_strip_k(const DsP& p, int nt, int ks, hipStream_t st) {
   return 0;
 }
 static int ds_strip_dispatch(const DsP& p, int k, hipStream_t st) {
-  static const bool off = [] { const char* v = getenv("EY_DS_STRIP"); return v && *v == '0'; }();
-  if (off) return 0;
+  if (!tune().ds_strip) return 0;
   const int nt = p.NTpack, ks = (p.Cin + 31) / 32;
   if (p.Cout > 16 * nt || ks > 2 || !p.vec_store || p.Cout % 4) return 0;
   if (p.Cin < 32) return 0;  // 16 channels would leave half of every wave's lanes (channel groups 2,3) idle: the LDS-tile kernel wins
@@ -641,7 +640,7 @@ extern "C" int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, i
   const int es = 2;
   // measured (tools/ds_bench.py): k = 7 always wins (85 -> 28 us at C16 160x160); k = 3/5 win once the map has >= 100k pixels
   // (33 -> 24 us), below that the register-strip kernel's extra waves matter more.  EY_TZ_KMASK (decimal bit mask over k) overrides.
-  static const long tz_kmask = ds_env("EY_TZ_KMASK", 168), tz_minpx = ds_env("EY_TZ_MINPX", 100000);
+  const long tz_kmask = tune().tz_kmask, tz_minpx = tune().tz_minpx;
   const bool fits = dtype == EY_F16 && w_dw_toeplitz && (k == 3 || k == 5 || k == 7) && ((tz_kmask >> k) & 1) && (k == 7 || (long)B * H * W >= tz_minpx) &&
                     (Cin == 16 || Cin == 32) && Cout <= 32 && Cout % 4 == 0 && x && y && w_pw_packed &&
                     x_cstride >= Cin && (x_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(w_dw_toeplitz, 16) && (y_cstride * es) % 8 == 0 && ey_aligned(y, 8) &&

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
       if (level == 0) break;
       --level;
       need_hist = true;
+      __syncthreads();  // every wave has read S.hist[H] / S.hist[0] before the next iteration zeroes the histogram
       continue;
     }
     // lowest-cost chunk: the largest bin_lo < H whose digit range [bin_lo, H) holds >= NMS_TARGET keys (else 0)

@@ -1,6 +1,7 @@
 // HBM-bound NHWC operators of the EdgeLine-YOLO forward path: stem conv, depthwise conv, Haar DWT, SPPF pooling,
 // slice copies / layout transposes, and the generic scalar direct convolution (correctness path for odd shapes).
 #include "common.h"
+#include "tune.h"
 #include <stdlib.h>
 
 // ============================================================================ generic direct conv (scalar)
@@ -241,7 +242,7 @@ extern "C" int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int
   EY_CHECK(y_cstride >= Cout && (y_cstride * es) % 16 == 0 && ey_aligned(y, 16), "stem: output view not 16-byte aligned");
   EY_CHECK(x_dtype != EY_F16 || (W % 2 == 0 && ey_aligned(x, 4)), "stem: f16 images need an even width (column pairs are fetched as 32-bit words)");
   hipStream_t st = (hipStream_t)stream;
-  static const bool stem_mfma_off = [] { const char* v = getenv("EY_STEM_MFMA"); return v && *v == '0'; }();
+  const bool stem_mfma_off = !tune().stem_mfma;
   if (x_dtype == EY_F16 && y_dtype == EY_F16 && Cin == 3 && W % 8 == 0 && Cout <= 64 && ey_aligned(x, 16) && !stem_mfma_off && (long)B * 3 * H * W * 2 < (1L << 31)) {
     switch (Cout / 16) {  // fp32-accumulated f16 products; the weights are rounded to f16 like every other conv of the f16 mode
       case 1: return stem_mfma_launch<1>(B, H, W, act, x, w, bias, y, y_cstride, st);

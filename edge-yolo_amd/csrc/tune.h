@@ -1,0 +1,36 @@
+// Dispatch tunables of libedgeyolo_hip.so.  Defaults are the measured optimum on MI355X; nothing reads the environment.
+// Developer tools change them through the C ABI (ey_tune_set / ey_tune_get, include/edgeyolo_hip.h); they select between
+// kernels that compute the same result, never the arithmetic itself.
+#pragma once
+struct EyTune {
+  long tiles_per_wave = 0;      // ws: minimum tiles per wave before adding workgroups (0 = fill all slots)
+  long mt2_min_m = 300000;      // ws: 2 pixel blocks per wave from this many output pixels
+  long small_m = 100000;        // small-M kernel below this many output pixels ...
+  long small_wmb = 48;          // ... while (#tiles x weight bytes) stays below this many MiB
+  long halo_min_c = 48;         // 3x3 halo kernel for Cin in [this, 64]
+  long ws_lds_kb = 76;          // ws: preferred LDS per workgroup in KiB (2 workgroups per CU)
+  long ws_wg_cu = 2;            // ws: workgroups per CU when LDS allows
+  long ws_k3_minnt = 0;         // 3x3: use the K-chunked kernel when the weight-stationary tile would cover fewer than this many 16-channel blocks (and not all of Cout)
+  long tile_wlds = 1;           // tile kernel weights through LDS: 0 never, 1 always, 2 for stride 1 only
+  long tile_s2_minc = 64;       // tile kernel for stride 2 only from this many input channels ...
+  long tile_s2_minm = 40000;    // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
+  long grid_div = 1;            // persistent kernels: launch 1/grid_div of the resident slots
+  long c3r = 1;                 // register-stationary 3x3 kernel for Cin == 16 (0 = off)
+  long tile_minwg = 400;        // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
+  long tile_flat = 1;           // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)
+  long tile_mink = 0;           // 3x3 tile kernel for K = 9*Cin >= this (huge value = off)
+  long pwr_m = 110000;          // register-stationary pointwise kernel from this many output pixels (huge value = off)
+  long pwr_frags = 24;          // pwr: at most this many weight fragments (k-steps x 16-channel blocks) per wave
+  long pw_m = 110000;           // lean pointwise kernel below this many output pixels (0 = off)
+  long pw_waves = 3072;         // pw: prefer the widest channel tile that still leaves this many waves
+  long pw_wmb = 64;             // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this many MiB
+  long ds_p = 0;                // dsconv strip kernel: force the strip length (0 = measured rule)
+  long tz_kmask = 168;          // Toeplitz dsconv kernel: bit k set = use it for kernel size k (168 = k 3, 5, 7)
+  long tz_minpx = 100000;       // ... k = 3/5 only on maps with at least this many pixels (k = 7 always)
+  long ds_strip = 1;            // dsconv register-strip kernel (0 = off)
+  long stem_mfma = 1;           // MFMA stem kernel (0 = VALU stem)
+  long linattn_mfma = 1;        // MFMA linear-attention kernel (0 = fp32 VALU kernel)
+  long softattn_mfma = 1;       // MFMA softmax-attention kernel (0 = fp32 VALU kernel)
+};
+extern EyTune g_ey_tune;
+static inline const EyTune& tune() { return g_ey_tune; }

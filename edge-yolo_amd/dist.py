@@ -36,41 +36,44 @@ def unpack_rows(packed, max_det):
 
 
 class BoxGatherer:
-    """Double-buffered all_gather of packed result rows.  On CUDA/ROCm it runs on its own stream: the producer stream
-    only waits for the staging copy of the previous call, so the collective overlaps the next batch."""
+    """All-gather of packed result rows, K = `every` batches per collective, double buffered.
+
+    own_stream=True (every forced to 1): pack + collective run on a stream of the gatherer's own; the producer stream only waits for
+    the staging copy, so the collective overlaps the next batch.  own_stream=False: pack + collective are enqueued on the caller's
+    current stream (for callers that already run the post-processing on a stream of its own: every extra ACTIVE stream costs
+    hardware-queue sharing with the forward graphs), and the rows of K consecutive batches are collected on the device and exchanged
+    by ONE all_gather (K x 230 KB per rank: still latency-bound); `flush()` sends a partial block.
+
+    Block layout on the wire: rank-major [rank][slot][image].  `results(j)` returns the rows of block j in GLOBAL batch order
+    (slot, rank, image) -- i.e. for every batch of the block the images of rank 0, then rank 1, ... -- and only for the slots that
+    were filled: unused slots of a partial block carry count 0 and are dropped."""
 
     def __init__(self, world, batch_local, max_det, device, group=None, own_stream=True, every=1):
-        """own_stream=False: pack + collective are enqueued on the caller's current stream (for callers that already run the
-        post-processing on a stream of its own: every extra active stream costs hardware-queue sharing with the forward graph).
-        every=K (own_stream=False only): the packed rows of K consecutive batches are collected on the device and exchanged by ONE
-        all_gather (K x 230 KB per rank: still latency-bound) -- the collective runs on the backend's internal stream, a fifth active
-        stream next to a 4-stage pipeline, which costs ~0.8 ms of hardware-queue aliasing each time it is active; `flush()` sends a
-        partial block."""
         self.world, self.B, self.max_det, self.group = world, batch_local, max_det, group
-        self.every = max(1, int(every)) if not own_stream else 1
-        self.slot = 0
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
-        w = max_det * 6 + 1
-        rows = batch_local * self.every
-        self.stage = [torch.zeros((rows, w), dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.gathered = [torch.zeros((world * rows, w), dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.i = 0
         self.side = torch.cuda.Stream(device=self.device) if (self.cuda and own_stream) else None
+        self.every = 1 if self.side is not None else max(1, int(every))
+        self.slot = 0
+        self.w = max_det * 6 + 1
+        rows = batch_local * self.every
+        self.stage = [torch.zeros((rows, self.w), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.gathered = [torch.zeros((world * rows, self.w), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.nslots = [0, 0]  # filled slots of the block each buffer holds
+        self.i = 0            # blocks exchanged so far; block k lives in buffer k & 1
         self.copied = [None, None]
         self.done = [None, None]
 
-    def __call__(self, boxes, count):
-        if self.cuda and self.side is None:
-            j = self.i & 1
-            pack_rows(boxes, count, self.stage[j][self.slot * self.B:(self.slot + 1) * self.B])
-            self.slot += 1
-            if self.slot == self.every:
-                self.flush()
-            return self.gathered[j]
-        j = self.i & 1
-        self.i += 1
+    def _exchange(self, j):
         if self.cuda:
+            dist.all_gather_into_tensor(self.gathered[j], self.stage[j], group=self.group)
+        else:
+            dist.all_gather(list(self.gathered[j].chunk(self.world)), self.stage[j], group=self.group)
+
+    def __call__(self, boxes, count):
+        """Add one batch.  Returns the index of the block that was exchanged by this call, or None while the block is still filling."""
+        j = self.i & 1
+        if self.side is not None:
             main = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(main)
@@ -79,28 +82,36 @@ class BoxGatherer:
                 pack_rows(boxes, count, self.stage[j])
                 copied = torch.cuda.Event()
                 copied.record(self.side)
-                dist.all_gather_into_tensor(self.gathered[j], self.stage[j], group=self.group)
+                self._exchange(j)
                 done = torch.cuda.Event()
                 done.record(self.side)
             main.wait_event(copied)  # the next replay may overwrite boxes/count only after they were staged
             self.copied[j], self.done[j] = copied, done
-        else:
-            pack_rows(boxes, count, self.stage[j])
-            parts = list(self.gathered[j].chunk(self.world))
-            dist.all_gather(parts, self.stage[j], group=self.group)
-        return self.gathered[j]
+            self.nslots[j] = 1
+            self.i += 1
+            return self.i - 1
+        pack_rows(boxes, count, self.stage[j][self.slot * self.B:(self.slot + 1) * self.B])
+        self.slot += 1
+        if self.slot == self.every:
+            return self.flush()
+        return None
 
     def flush(self):
-        """(own_stream=False) exchange the block collected so far, complete or not (unused slots hold the previous block's rows)."""
-        if not (self.cuda and self.side is None) or self.slot == 0:
-            return
+        """(own_stream=False) exchange the block collected so far, complete or not.  Returns its index, or None if it was empty."""
+        if self.side is not None or self.slot == 0:
+            return None
         j = self.i & 1
-        self.i += 1
+        if self.slot < self.every:
+            self.stage[j][self.slot * self.B:, self.max_det * 6].zero_()  # unused slots: count 0 (their rows are stale, never unpacked)
+        self.nslots[j] = self.slot
         self.slot = 0
-        dist.all_gather_into_tensor(self.gathered[j], self.stage[j], group=self.group)
-        done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(self.device))
-        self.done[j] = done
+        self._exchange(j)
+        if self.cuda:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self.done[j] = done
+        self.i += 1
+        return self.i - 1
 
     def wait(self):
         if self.cuda and self.side is not None:
@@ -110,9 +121,14 @@ class BoxGatherer:
                 if d is not None:
                     torch.cuda.current_stream(self.device).wait_event(d)
 
-    def results(self, j=None):
-        j = (self.i - 1) & 1 if j is None else j
+    def results(self, block=None):
+        """Rows of an exchanged block (default: the newest), as a list of (n_i, 6) tensors in global batch order (slot, rank, image)."""
+        if self.i == 0:
+            return []
+        k = self.i - 1 if block is None else block
+        j = k & 1
         self.wait()
         if self.cuda:
             torch.cuda.current_stream(self.device).synchronize()
-        return unpack_rows(self.gathered[j], self.max_det)
+        g = self.gathered[j].view(self.world, self.every, self.B, self.w)[:, : self.nslots[j]]
+        return unpack_rows(g.permute(1, 0, 2, 3).reshape(-1, self.w), self.max_det)

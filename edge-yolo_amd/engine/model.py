@@ -9,7 +9,9 @@ from ..nn.tasks import DetectionModel, guess_model_task, torch_safe_load_state, 
 
 
 class Model(torch.nn.Module):
-    def __init__(self, model="yolo11n.yaml", task=None, verbose=False):
+    def __init__(self, model="yolo11n.yaml", task=None, verbose=False, nc=None):
+        """nc (extension): number of classes for a model built from a YAML (the reference takes it from the dataset YAML at train time,
+        engine/trainer.py; checkpoints written by save() carry it)."""
         super().__init__()
         self.predictor = None
         self.model = None
@@ -18,36 +20,52 @@ class Model(torch.nn.Module):
         self.task = task
         model = str(model).strip()
         if Path(model).suffix in {".yaml", ".yml"}:
-            self._new(model, task=task, verbose=verbose)
+            self._new(model, task=task, verbose=verbose, nc=nc)
         else:
             self._load(model, task=task)
 
-    def _new(self, cfg, task=None, model=None, verbose=False):
-        cfg_dict = yaml_model_load(cfg)
+    def _new(self, cfg, task=None, model=None, verbose=False, nc=None):
+        cfg_dict = cfg if isinstance(cfg, dict) else yaml_model_load(cfg)
         self.cfg = cfg
         # the reference raises NotImplementedError here for GFLHeadv2_uniH YAMLs unless task="detect" is passed
         # (engine/model.py:1096-1103 via tasks.py:1198-1210); the argument is accepted but not required
         self.task = task or guess_model_task(cfg_dict)
         if self.task != "detect":
             raise NotImplementedError(f"task '{self.task}': only 'detect' is built")
-        self.model = DetectionModel(cfg_dict, verbose=verbose)
+        self.model = DetectionModel(cfg_dict, nc=nc, verbose=verbose)
         self.overrides["model"] = self.cfg
         self.overrides["task"] = self.task
         self.model.task = self.task
-        self.model_name = cfg
+        self.model_name = cfg_dict.get("yaml_file", "model") if isinstance(cfg, dict) else cfg
 
     def _load(self, weights, task=None):
-        """Tensor-only checkpoints written by `save()`: {'yaml': <name or dict>, 'nc': int, 'state_dict': {...}}.
-        Pickled reference checkpoints (module objects, tasks.py:815-955) are never unpickled here."""
+        """Tensor-only checkpoints written by `save()`: {'yaml': <name or dict>, 'nc': int, 'fused': bool, 'state_dict': {...}}.
+        Pickled reference checkpoints (module objects, tasks.py:815-955) are never unpickled here; tools/export_reference_weights.py
+        turns one into this format on a machine that has the reference installed."""
         ck = torch_safe_load_state(weights)
         if not isinstance(ck, dict) or "state_dict" not in ck or "yaml" not in ck:
             raise ValueError(f"{weights}: expected a tensor-only checkpoint with 'yaml' and 'state_dict' entries (see YOLO.save)")
-        self._new(ck["yaml"], task=task)
-        self.model.load(ck["state_dict"])
+        cfg = ck["yaml"]
+        if ck.get("nc") is not None:
+            cfg = dict(yaml_model_load(cfg)) if not isinstance(cfg, dict) else dict(cfg)
+            cfg["nc"] = int(ck["nc"])
+        self._new(cfg, task=task)
+        if bool(ck.get("fused", False)):
+            self.model.fuse()  # the checkpoint holds BN-folded conv weights + biases (saved after predict()): same module layout first
+        loaded, own = self.model.load(ck["state_dict"])
+        if loaded != own:
+            missing = sorted(set(self.model.state_dict()) - set(ck["state_dict"]))[:5]
+            raise ValueError(f"{weights}: only {loaded} of {own} model tensors were found in the checkpoint (e.g. missing {missing}); "
+                             "was it saved from a different YAML / nc, or fused without the 'fused' flag?")
         self.ckpt_path = weights
 
     def save(self, filename):
-        torch.save({"yaml": self.cfg, "nc": self.model.yaml["nc"], "state_dict": self.model.state_dict()}, filename)
+        """Tensor-only checkpoint (readable with torch.load(weights_only=True)).  predict() folds BatchNorm into the convs in place
+        (reference AutoBackend does the same, autobackend.py:144-155); the 'fused' flag records which layout the tensors have."""
+        m = self.model
+        sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in m.state_dict().items()}
+        torch.save({"yaml": m.yaml.get("yaml_file", self.cfg) if isinstance(self.cfg, dict) else self.cfg, "nc": int(m.yaml["nc"]),
+                    "fused": bool(m.convs_folded()), "state_dict": sd}, filename)
 
     def load(self, weights):
         """Load a flat state_dict (dict or tensor-only file) keyed like the reference's `model.N....` entries."""
@@ -106,11 +124,13 @@ class Model(torch.nn.Module):
     __call__ = predict
 
     def predict_batches(self, batches, stages=4, **kwargs):
-        """Throughput form of predict(): a generator over an iterable of BCHW float tensors in [0,1] (all of one shape) that yields one
-        list of Results per batch, in order.  The layer list is cut into `stages` pipeline stages (engine/predictor.py::PipelinedRunner:
-        one hipGraph and one HIP stream per stage; batch i's head/NMS run beside batch i+1's neck and batch i+2's backbone), so the
-        results of a batch arrive `stages - 1` submissions later.  Same kwargs as predict() (conf, iou, max_det, half, agnostic_nms,
-        classes, device).  The reference has no counterpart (its stream=True generator still runs one batch at a time)."""
+        """Throughput form of predict(): a generator over an iterable of BCHW float tensors in [0,1] (all of one shape; host or device,
+        pinned host fp16/fp32 tensors upload fastest) that yields one list of Results per batch, in order.  The layer list is cut into
+        `stages` pipeline stages (engine/predictor.py::PipelinedRunner: one hipGraph and one HIP stream per stage; batch i's head/NMS
+        run beside batch i+1's neck and batch i+2's backbone), host batches are uploaded on a copy stream under the batches in flight,
+        and the detection counts come back through a pinned buffer, so the only host waits are on events.  The results of a batch
+        arrive `stages - 1` submissions later.  Same kwargs as predict() (conf, iou, max_det, half, agnostic_nms, classes, device).
+        The reference has no counterpart (its stream=True generator still runs one batch at a time)."""
         from .predictor import PipelinedRunner
         from ..utils import ops
         args = {"conf": 0.25, "iou": 0.7, "max_det": 300, "half": False, "agnostic_nms": False, "classes": None, "device": None}
@@ -118,49 +138,65 @@ class Model(torch.nn.Module):
         if unknown:
             raise TypeError(f"predict_batches() got unsupported arguments {sorted(unknown)}")
         args.update({k: v for k, v in kwargs.items() if k in args})
-        pipe, post, pending, nset = None, None, [], 0
-        for x in batches:
-            if pipe is None:
-                device = self._select_device(args["device"] if args["device"] is not None else (x.device if x.is_cuda else None))
-                m = self.model.to(device)
-                m.fuse()
-                m = (m.half() if args["half"] else m.float()).eval()
-                post = DetectionPredictor(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
-                                          agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=False)
-                n = len(m.model)
-                stages = max(2, min(int(stages), n))
-                cuts = sorted({max(1, round(0.39 * (n - 1))), max(2, round(0.87 * (n - 1))), n - 1})[-(stages - 1):]
-                bounds = [0] + cuts + [n]
-                fns = [(lambda st, lo=lo, hi=hi: m.forward_layers(st if lo else (st, []), lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
-                last = fns.pop()
-                fns.append(lambda st, last=last: ops.nms_device(last(st)[0][0], args["conf"], args["iou"], args["classes"], args["agnostic_nms"], args["max_det"])[:2])
-                import edge_yolo_amd.nn.modules.head as _hm
-                fork, _hm._HEAD_STREAMS = _hm._HEAD_STREAMS, False  # the head is a pipeline stage of its own: no fork inside it while capturing
-                try:
-                    pipe = PipelinedRunner(*fns, post.preprocess(x))
-                finally:
-                    _hm._HEAD_STREAMS = fork
-                nset = pipe.n
-            im = post.preprocess(x)
-            while pending and (len(pending) >= nset or pending[0][0] == pipe.i % nset):  # the buffer set about to be reused must be read first
-                yield self._finish(pipe, post, *pending.pop(0))
-            pending.append((pipe.submit(im), im))
-        while pending:
-            yield self._finish(pipe, post, *pending.pop(0))
+        pipe, post, pending, nset, dev_ctx = None, None, [], 0, None
+        try:
+            for x in batches:
+                if pipe is None:
+                    device = self._select_device(args["device"] if args["device"] is not None else (x.device if x.is_cuda else None))
+                    dev_ctx = torch.cuda.device(device)
+                    dev_ctx.__enter__()
+                    m = self.model.to(device)
+                    m.fuse()
+                    m = (m.half() if args["half"] else m.float()).eval()
+                    post = DetectionPredictor(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
+                                              agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=False)
+                    n = len(m.model)
+                    stages = max(2, min(int(stages), n))
+                    cuts = sorted({max(1, round(0.39 * (n - 1))), max(2, round(0.87 * (n - 1))), n - 1})[-(stages - 1):]
+                    bounds = [0] + cuts + [n]
+                    fns = [(lambda st, lo=lo, hi=hi: m.forward_layers(st if lo else (st, []), lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+                    last = fns.pop()
+                    fns.append(lambda st, last=last: ops.nms_device(last(st)[0][0], args["conf"], args["iou"], args["classes"], args["agnostic_nms"], args["max_det"])[:2])
+                    head = m.model[-1]
+                    fork, head.head_streams = getattr(head, "head_streams", False), False  # the head is a pipeline stage of its own: no fork inside it
+                    try:
+                        pipe = PipelinedRunner(*fns, post.preprocess(x), copy_stream=True)
+                    finally:
+                        head.head_streams = fork
+                    nset = pipe.n
+                    counts = [torch.empty(x.shape[0], dtype=torch.int32).pin_memory() for _ in range(nset)]
+                    ready = [torch.cuda.Event() for _ in range(nset)]
+                    dt = torch.float16 if args["half"] else torch.float32
+                if not x.is_cuda and x.dtype != dt:  # a dtype-changing H2D copy would convert on the host: upload as is, convert on the device
+                    x = post.preprocess(x)
+                elif x.dim() != 4 or tuple(x.shape) != tuple(pipe.static_input(0).shape):
+                    raise ValueError(f"predict_batches: every batch must have shape {tuple(pipe.static_input(0).shape)}, got {tuple(x.shape)}")
+                while pending and (len(pending) >= nset or pending[0] == pipe.i % nset):  # the buffer set about to be reused must be read first
+                    yield self._finish(pipe, post, pending.pop(0), counts, ready)
+                j = pipe.submit(x)
+                with torch.cuda.stream(pipe.sp):  # counts -> pinned host memory right behind this batch's NMS; the host later waits on the event only
+                    counts[j].copy_(pipe.outputs(j)[1], non_blocking=True)
+                    ready[j].record(pipe.sp)
+                pending.append(j)
+            while pending:
+                yield self._finish(pipe, post, pending.pop(0), counts, ready)
+        finally:
+            if dev_ctx is not None:
+                dev_ctx.__exit__(None, None, None)
 
     @staticmethod
-    def _finish(pipe, post, j, im):
-        pipe.wait(j)
-        boxes, count = pipe.outputs(j)
+    def _finish(pipe, post, j, counts, ready):
+        ready[j].synchronize()
+        boxes, _ = pipe.outputs(j)
         post._orig = None
-        return post.postprocess(boxes, count, im, None)
+        return post.postprocess(boxes, counts[j], pipe.static_input(j), None)
 
 
 class YOLO(Model):
     """YOLO detect model (reference models/yolo/model.py:11-59)."""
 
-    def __init__(self, model="yolo11n.yaml", task=None, verbose=False):
-        super().__init__(model=model, task=task, verbose=verbose)
+    def __init__(self, model="yolo11n.yaml", task=None, verbose=False, nc=None):
+        super().__init__(model=model, task=task, verbose=verbose, nc=nc)
 
     @property
     def task_map(self):

@@ -81,11 +81,14 @@ class PipelinedRunner:
     PipelinedRunner(f1, f2, ..., example): stage functions chained (stage k gets stage k-1's return value), example = input batch.
     """
 
-    def __init__(self, *args, warmup=2):
+    def __init__(self, *args, warmup=2, copy_stream=False):
+        """copy_stream=True: batches handed to submit(x) are copied into the stage-0 input buffer on a stream of their own (host
+        tensors: one H2D DMA per batch that overlaps the compute of the batches in flight) instead of on the first stage's stream."""
         *stages, example = args
         dev = example.device
         self.dev, self.n = dev, len(stages)
         self.streams = [torch.cuda.Stream(device=dev) for _ in stages]
+        self.copy_stream = torch.cuda.Stream(device=dev) if copy_stream else None
         self.sf, self.sp = self.streams[0], self.streams[-1]
         self.sets = []
         cur = torch.cuda.current_stream(dev)
@@ -124,10 +127,22 @@ class PipelinedRunner:
         st = self.sets[j]
         cur = torch.cuda.current_stream(self.dev)
         self.streams[0].wait_stream(cur)
+        copied = None
+        if self.copy_stream is not None and x is not None and x.data_ptr() != st["x"].data_ptr():
+            cs = self.copy_stream
+            cs.wait_stream(cur)
+            cs.wait_event(st["done"][-1])  # every stage of the batch that used this buffer set n submits ago is done (stage 0 read its input long before)
+            with torch.cuda.stream(cs):
+                st["x"].copy_(x, non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(cs)
+            x = None
         for s, (stream, g) in enumerate(zip(self.streams, st["graphs"])):
             with torch.cuda.stream(stream):
                 # stage 0 waits for the LAST stage of the batch that used this buffer set n submits ago; stage s for stage s-1 of this batch
                 stream.wait_event(st["done"][-1] if s == 0 else st["done"][s - 1])
+                if s == 0 and copied is not None:
+                    stream.wait_event(copied)
                 if s == 0 and x is not None and x.data_ptr() != st["x"].data_ptr():
                     st["x"].copy_(x, non_blocking=True)
                 g.replay()
@@ -144,8 +159,10 @@ class PipelinedRunner:
 
 
 class DetectionPredictor:
-    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True):
-        self.model, self.device, self.half = model, device, half
+    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True, validate_input=False):
+        """validate_input=True re-enables the reference's value-range check of tensor sources (data/loaders.py:554-560: max > 1 is an
+        error there); it costs a device reduction and a host sync per call, so it is opt-in."""
+        self.model, self.device, self.half, self.validate_input = model, device, half, validate_input
         self.conf, self.iou, self.max_det, self.agnostic_nms, self.classes = conf, iou, max_det, agnostic_nms, classes
         self._lock = threading.Lock()
         self.runner = GraphRunner(self._device_step) if graph else self._device_step
@@ -166,9 +183,11 @@ class DetectionPredictor:
             im = im[None]
         if im.dim() != 4 or im.shape[2] % 32 or im.shape[3] % 32:
             raise ValueError(f"input tensor should be BCHW with H,W multiples of 32, got {tuple(im.shape)}")
-        if im.is_floating_point() and im.numel() and float(im.max()) > 1.0 + 1e-5:
+        if not im.is_floating_point():
+            raise TypeError("tensor sources must be floating point images in [0,1] (uint8 HWC BGR images go in as numpy arrays)")
+        if self.validate_input and im.numel() and float(im.max()) > 1.0 + 1e-5:
             raise ValueError("torch.Tensor inputs should be normalized 0.0-1.0")
-        im = im.to(self.device)
+        im = im.to(self.device, non_blocking=True)
         return (im.half() if self.half else im.float()).contiguous()
 
     def _letterbox_batch(self, ims, new_shape=640):
@@ -182,7 +201,7 @@ class DetectionPredictor:
         return lb.batch(self._orig, self.device, torch.float16 if self.half else torch.float32)
 
     def __call__(self, source):
-        with self._lock:
+        with self._lock, torch.cuda.device(self.device):  # kernels go to the CURRENT device's stream (_lib.stream)
             self._orig = None
             prof = (Profile(self.device), Profile(self.device), Profile(self.device))
             with prof[0]:
@@ -202,14 +221,15 @@ class DetectionPredictor:
         boxes = boxes.clone()
         results = []
         names = self.model.names
+        if self._orig is None:  # tensor source: original image == network input: one clip over the whole batch (4 launches, not 4 per image)
+            ops.clip_boxes(boxes, img.shape[2:])
         for i in range(len(n)):
             det = boxes[i, : n[i]]
             if self._orig is not None:
                 orig = self._orig[i]
                 det[:, :4] = ops.scale_boxes(img.shape[2:], det[:, :4], orig.shape)
-            else:  # tensor source: original image == network input
+            else:
                 orig = None
-                det[:, :4] = ops.clip_boxes(det[:, :4], img.shape[2:])
             r = Results(orig, path=f"image{i}.jpg", names=names, boxes=det)
             if orig is None:
                 r.orig_shape = tuple(img.shape[2:])

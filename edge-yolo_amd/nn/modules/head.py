@@ -3,9 +3,7 @@
 depthwise kernels; everything after them (DGQP statistics + quality FCs, DFL softmax-expectation, anchor decode,
 score modulation) is ONE fused kernel per pyramid level writing the (B, 4+nc, A) fp32 prediction tensor.
 """
-import copy
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -17,11 +15,6 @@ from ... import _lib as L
 
 __all__ = ("Detect", "GF2Detect", "GFLHeadv2_uniH")
 
-
-_HEAD_STREAMS = os.environ.get("EY_HEAD_STREAMS", "1") != "0"
-_CHAIN = os.environ.get("EY_HEAD_CHAIN", "1") != "0"  # fuse the last two 1x1 convs of the class tower (ey_conv_pw_chain)
-# developer override: stream index (0 = the caller's stream) of each tower in order (level0 box, level0 cls, level1 box, ...)
-_HEAD_MAP = [int(v) for v in os.environ["EY_HEAD_MAP"].split(",")] if os.environ.get("EY_HEAD_MAP") else None
 
 class _Plain(_Packed):
     """Weights of a bare nn.Conv2d(+bias) 1x1 tower tail, packed for the MFMA conv."""
@@ -47,6 +40,14 @@ class Detect(nn.Module):
     anchors = torch.empty(0)
     strides = torch.empty(0)
     legacy = False
+    # Execution options (instance attributes; they never change results):
+    #  head_streams: run the towers of the smaller pyramid levels on a second HIP stream (a parallel hipGraph branch).  A caller
+    #                that already runs the head as a pipeline stage of its own (YOLO.predict_batches, bench.py) sets it False.
+    #  tower_streams: optional stream index (0 = the caller's stream) per tower in order (level0 box, level0 cls, level1 box, ...)
+    #  chain: fuse the last two 1x1 convs of the class tower into one register-only kernel (ey_conv_pw_chain)
+    head_streams = True
+    tower_streams = None
+    chain = True
 
     def __init__(self, nc=80, ch=()):
         super().__init__()
@@ -67,6 +68,14 @@ class Detect(nn.Module):
         )
         self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
         self._tails = {}
+        # packed tails / quality-head weights are caches of parameters: drop them whenever parameters are (re)loaded
+        self.register_load_state_dict_post_hook(lambda m, _keys: m._reset_caches())
+
+    def _reset_caches(self):
+        self._tails = {}
+        self._stride_f = None
+        if hasattr(self, "_qcache"):
+            self._qcache = {}
 
     # ---- towers
     def _tail(self, conv):
@@ -76,8 +85,7 @@ class Detect(nn.Module):
         return t
 
     def _apply(self, fn, *a, **k):
-        self._tails = {}
-        self._stride_f = None
+        self._reset_caches()
         return super()._apply(fn, *a, **k)
 
     def _box_tower(self, i, x, raw):
@@ -93,7 +101,7 @@ class Detect(nn.Module):
         last = c[-2]
         # non-legacy tower (head.py:68-70): ... -> DWConv -> Conv(c3,c3,1)+SiLU -> nn.Conv2d(c3,nc,1): the last two 1x1 convs run as ONE
         # register-only kernel when the shape fits (ey_conv_pw_chain), the intermediate (B,c3,H,W) tensor never exists
-        if (_CHAIN and isinstance(last, nn.Sequential) and len(last) == 2 and isinstance(last[0], DWConv) and isinstance(last[1], Conv)
+        if (self.chain and isinstance(last, nn.Sequential) and len(last) == 2 and isinstance(last[0], DWConv) and isinstance(last[1], Conv)
                 and last[1].conv.kernel_size == (1, 1) and isinstance(last[1].act, nn.SiLU) and x.dtype == torch.float16):
             for j in range(len(c) - 2):
                 t = c[j](t)
@@ -146,11 +154,11 @@ class Detect(nn.Module):
         # The towers of the pyramid levels are independent: the small levels run on a second HIP stream (fork / join around them),
         # which a captured hipGraph records as a parallel branch -- the 20x20 and 40x40 towers (a few hundred workgroups per kernel)
         # then run beside the 80x80 ones instead of after them (2.18 -> 2.08 ms/step).  More branches are slower (3 level streams
-        # 2.38 ms, 6 tower streams 2.40 ms: the persistent kernels fight for the CUs).  EY_HEAD_STREAMS=0 keeps one stream.
-        fork = _HEAD_STREAMS and dev.type == "cuda" and len(xs) > 1
+        # 2.38 ms, 6 tower streams 2.40 ms: the persistent kernels fight for the CUs).  `head_streams = False` keeps one stream.
+        fork = self.head_streams and dev.type == "cuda" and len(xs) > 1
         cur = torch.cuda.current_stream(dev) if fork else None
         # default: the first (largest) level on the caller's stream, all smaller levels one after the other on ONE side stream
-        smap = _HEAD_MAP if (_HEAD_MAP and len(_HEAD_MAP) == 2 * len(xs)) else [0, 0] + [1] * (2 * len(xs) - 2)
+        smap = list(self.tower_streams) if (self.tower_streams and len(self.tower_streams) == 2 * len(xs)) else [0, 0] + [1] * (2 * len(xs) - 2)
         if fork and (getattr(self, "_side", None) is None or self._side_dev != dev or len(self._side) != max(smap)):
             self._side, self._side_dev = [torch.cuda.Stream(device=dev) for _ in range(max(smap))], dev
         # every buffer a side stream WRITES is allocated before the fork: a block handed out later on the caller's stream could be one
@@ -204,7 +212,7 @@ class Detect(nn.Module):
         for a, b, s in zip(self.cv2, self.cv3, self.stride):
             a[-1].bias.data[:] = 1.0
             b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
-        self._tails = {}
+        self._reset_caches()
 
 
 class GF2Detect(Detect):
@@ -222,10 +230,6 @@ class GF2Detect(Detect):
             nn.Sequential(nn.Conv2d(in_stat, self.reg_channels, 1, bias=True), nn.ReLU(inplace=True), nn.Conv2d(self.reg_channels, 1, 1, bias=True),
                           nn.Sigmoid()) for _ in ch)
         self._qcache = {}
-
-    def _apply(self, fn, *a, **k):
-        self._qcache = {}
-        return super()._apply(fn, *a, **k)
 
     def _quality_params(self, i, device):
         if not self.apply_quality_in_inference:

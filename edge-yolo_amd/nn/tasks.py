@@ -136,6 +136,9 @@ class BaseModel(nn.Module):
     def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
         if profile or visualize or embed:
             raise NotImplementedError("profile/visualize/embed hooks are not part of the built path")
+        if torch.is_tensor(x) and x.is_cuda and x.device.index != torch.cuda.current_device():
+            with torch.cuda.device(x.device):  # launches go to the current device's stream (_lib.stream)
+                return self._predict_once(x)
         return self._predict_once(x)  # augment=True falls back to single scale exactly as the reference does (:181-187)
 
     def _predict_once(self, x, profile=False, visualize=False, embed=None):
@@ -178,6 +181,11 @@ class BaseModel(nn.Module):
                 if isinstance(m, Conv) and hasattr(m, "bn"):
                     m.fuse_bn()
         return self
+
+    def convs_folded(self):
+        """True once fuse() ran: no Conv/DWConv still carries its BatchNorm (DSConv BatchNorms stay modules by design, so the
+        reference's count-based is_fused() below says False for EdgeLine YAMLs even after fuse(); checkpoints record this flag)."""
+        return not any(isinstance(m, Conv) and hasattr(m, "bn") for m in self.model.modules())
 
     def is_fused(self, thresh=10):
         bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)

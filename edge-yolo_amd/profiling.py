@@ -71,7 +71,25 @@ def _pmc_traffic(kernel):
     return (k["hbm_bytes_per_launch"], os.path.basename(files[-1])) if k else (None, None)
 
 
-def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
+def _price(bytes_per, flops_per, avg_us, hbm_peak_gbs, mfma_peak_tflops):
+    """bound + achieved + frac of one kernel: MFMA-bound when its arithmetic intensity exceeds the machine balance, else HBM-bound."""
+    balance = mfma_peak_tflops * 1e12 / (hbm_peak_gbs * 1e9)
+    if flops_per / max(bytes_per, 1.0) >= balance:
+        ach = flops_per / (avg_us * 1e-6) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 3), "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": round(ach / mfma_peak_tflops, 4)}
+    ach = bytes_per / (avg_us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(ach / hbm_peak_gbs, 4)}
+
+
+def step_roofline(step_fn, steps, ms_per_step, hbm_peak_gbs, mfma_peak_tflops, csv_path=None):
+    """The `roofline` object of bench.py: an instrumented eager pass of the same step brackets every launch with HIP events on the
+    launch stream and aggregates by kernel instantiation (the grouping of `rocprofv3 --stats`).
+
+    * top level = the DOMINANT kernel (largest share of traced device time, NMS included): bound / achieved / peak / frac / traffic;
+    * `table`  = every kernel: launches per step, average launch us, algorithmic bytes and FLOPs per launch, bound, frac -- so every
+      fraction can be recomputed from the committed file (csv_path writes the same rows as CSV for profiles/);
+    * `step`   = whole-step view against the measured ms_per_step of the timed (pipelined) run: algorithmic bytes / FLOPs of all
+      launches of one step divided by the step time, as fractions of the HBM and dense-f16 MFMA peaks."""
     step_fn()
     torch.cuda.synchronize()
     with trace() as t:
@@ -84,30 +102,40 @@ def dominant_kernel_roofline(step_fn, steps, hbm_peak_gbs, mfma_peak_tflops):
             torch.cuda.synchronize()
     agg = t.summary()
     total = sum(a["ms"] for a in agg.values())
-    # The roofline is priced for the dominant kernel of the FORWARD stage.  The NMS stage (key build + per-image greedy
-    # suppression: one workgroup per image, inherently sequential, neither HBM- nor MFMA-bound) runs on the post-processing stream
-    # under the next batch's forward; it stays in top5 and its time is inside `value`, but a bandwidth fraction says nothing about it.
-    name, a = max(((k, v) for k, v in agg.items() if not k.startswith("nms(")), key=lambda kv: kv[1]["ms"])
-    avg_us = a["ms"] * 1e3 / a["launches"]
-    bytes_per = a["bytes"] / a["launches"]
-    flops_per = a["flops"] / a["launches"]
-    balance = mfma_peak_tflops * 1e12 / (hbm_peak_gbs * 1e9)
-    out = {"kernel": name, "launches_per_step": a["launches"] // steps, "avg_launch_us": round(avg_us, 3),
-           "share_of_traced_device_time": round(a["ms"] / total, 4)}
-    if flops_per / max(bytes_per, 1.0) >= balance:
-        ach = flops_per / (avg_us * 1e-6) / 1e12
-        out.update({"bound": "mfma", "achieved": round(ach, 3), "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": round(ach / mfma_peak_tflops, 4)})
-    else:
-        ach = bytes_per / (avg_us * 1e-6) / 1e9
-        out.update({"bound": "hbm", "achieved": round(ach, 2), "peak": hbm_peak_gbs, "unit": "GB/s", "frac": round(ach / hbm_peak_gbs, 4)})
-    out["alg_bytes_per_launch"] = int(bytes_per)
-    out["alg_flops_per_launch"] = int(flops_per)
+    rows = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        n = a["launches"]
+        avg_us, bytes_per, flops_per = a["ms"] * 1e3 / n, a["bytes"] / n, a["flops"] / n
+        r = {"kernel": k, "launches_per_step": round(n / steps, 2), "avg_launch_us": round(avg_us, 3), "ms_per_step": round(a["ms"] / steps, 4),
+             "share": round(a["ms"] / total, 4), "alg_bytes_per_launch": int(bytes_per), "alg_flops_per_launch": int(flops_per)}
+        r.update(_price(bytes_per, flops_per, avg_us, hbm_peak_gbs, mfma_peak_tflops))
+        rows.append(r)
+    top = rows[0]
+    out = {"kernel": top["kernel"], "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
+           "share_of_traced_device_time": top["share"]}
+    out.update({k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "alg_flops_per_launch")})
     # HBM bytes per launch from PMC counters: they need their own rocprofv3 passes, so the number comes from the committed
     # summary of the newest pass over this same bench command (null when that pass did not see this kernel)
-    out["traffic"], src = _pmc_traffic(name)
+    out["traffic"], src = _pmc_traffic(top["kernel"])
     if src:
         out["traffic_source"] = "profiles/" + src
-    out["scope"] = "dominant kernel of the forward stage; nms(score+sort_greedy) is latency-bound (one workgroup per image) and overlapped on the post-processing stream"
-    out["top5"] = [{"kernel": k, "ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": v["launches"] // steps}
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:5]]
+    out["scope"] = ("dominant kernel = largest share of the traced device time of one step (every kernel of the step is in `table`, the NMS "
+                    "stage included); averages from HIP events on the launch stream over an instrumented eager pass of the same step")
+    step_bytes = sum(a["bytes"] for a in agg.values()) / steps
+    step_flops = sum(a["flops"] for a in agg.values()) / steps
+    sec = ms_per_step * 1e-3
+    out["step"] = {"launches_per_step": round(sum(a["launches"] for a in agg.values()) / steps, 1), "traced_device_ms_per_step": round(total / steps, 4),
+                   "alg_bytes_per_step": int(step_bytes), "alg_flops_per_step": int(step_flops),
+                   "hbm_frac": round(step_bytes / sec / (hbm_peak_gbs * 1e9), 4), "mfma_frac": round(step_flops / sec / (mfma_peak_tflops * 1e12), 4),
+                   "ms_per_step": ms_per_step}
+    out["table"] = rows
+    if csv_path:
+        import csv
+        cols = ["kernel", "launches_per_step", "avg_launch_us", "ms_per_step", "share", "alg_bytes_per_launch", "alg_flops_per_launch", "bound", "achieved", "peak",
+                "unit", "frac"]
+        with open(csv_path, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=cols)
+            w.writeheader()
+            for r in rows:
+                w.writerow({c: r[c] for c in cols})
     return out

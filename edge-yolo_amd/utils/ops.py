@@ -59,6 +59,9 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     nc = nc or (prediction.shape[1] - 4)
     if prediction.shape[1] - nc - 4:
         raise NotImplementedError("mask/keypoint channels (nm>0) are outside the detect path")
+    if prediction.is_cuda and prediction.device.index != torch.cuda.current_device():
+        with torch.cuda.device(prediction.device):  # launches go to the current device's stream (_lib.stream)
+            return nms_device(prediction, conf_thres, iou_thres, classes, agnostic, max_det, nc, max_nms, max_wh, multi_label)
     p = prediction.float().contiguous()
     mask = None
     if classes is not None:

@@ -36,6 +36,12 @@ const char* ey_last_error(void);
 int ey_version(void);
 /* sizeof(ey_conv_desc) (which=0) / sizeof(ey_conv_direct_desc) (which=1) as compiled: lets a binding check its struct layout. */
 size_t ey_abi_sizeof(int which);
+/* Dispatch tunables (developer tools only; csrc/tune.h lists the names and the measured defaults).  They choose between kernels
+ * that compute the same result -- thresholds such as "lean pointwise kernel below pw_m output pixels" -- never the arithmetic.
+ * The library reads NO environment variables.  ey_tune_set returns EY_EINVAL for an unknown name; ey_tune_get returns -1.
+ * Process-wide, not synchronised: set them before the first launch. */
+int ey_tune_set(const char* name, long value);
+long ey_tune_get(const char* name);
 
 /* ---- K1: dense convolution (+ folded-BN bias, activation, residual) as NHWC implicit GEMM on MFMA ------------
  * Replaces Conv.forward_fuse (nn/modules/conv.py:57-59, BN folded by utils/torch_utils.py:238-265), the raw
@@ -85,9 +91,11 @@ size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k);
  * MFMA epilogue, + zero slack).  Upload `out` to the device afterwards. */
 int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const float* w_oihw_host, void* out_host, size_t out_bytes);
 int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream);
-/* Kernel instantiation ey_conv2d launches for a shape (profiling only): kind*1000 + NT*10 + MT, kind 2 =
- * conv3_halo_kernel<T,NT,stride> (3x3, LDS halo tile), 1 = conv_ws_kernel<T,NT,MT,k> (weight-stationary persistent),
- * 0 = conv_igemm_kernel<T,NT,MT> (K-chunked fallback).  plain_single_source = one source, no upsample. */
+/* Kernel instantiation ey_conv2d launches for a shape (profiling only): kind*1000 + NT*10 + MT, kind 3 =
+ * conv_small_kernel<T,NT,BATCH> (small-M latency kernel), 2 = conv3_halo_kernel<T,NT,stride> (3x3, LDS halo tile),
+ * 1 = conv_ws_kernel<T,NT,MT,k> (weight-stationary persistent), 0 = conv_igemm_kernel<T,NT,MT> (K-chunked fallback).
+ * plain_single_source = one source, no upsample.  Shapes taken by the pointwise / tile / register-stationary kernels are
+ * reported by ey_conv_last_variant() after the launch. */
 int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_single_source, long M, int ngroup);
 /* Code of the kernel the last ey_conv2d on this thread launched when ey_conv_variant() does not describe it (else 0):
  * 4000 + NT*10 + nsrc = conv_pw_kernel<T,NT,...> (lean pointwise kernel for small maps); 5000 + NT*10 + KS =

@@ -11,7 +11,7 @@ reference files listed in SURVEY.md §8(c).  Every function cites the reference 
 
 Pinning: `tests/golden/*.npz` were produced by importing the real reference in the build container
 (`tests/golden/make_golden.py`, recipe = SURVEY.md Appendix C) on weights/inputs synthesised by
-`oracle/synth.py`; `tests/test_oracle_golden.py` checks this oracle against them.
+`synthdata.py` (repo root); `tests/test_oracle_golden.py` checks this oracle against them.
 The one boundary that is NOT pinned is `torchvision.ops.nms` (third-party, torchvision==0.17.2,
 absent from the reference tree and from this image): `oracle/nms.py::tv_nms` restates its published
 CPU algorithm; "parity unpinned" at that boundary.  The surrounding `non_max_suppression` logic is

@@ -1,6 +1,7 @@
-"""Deterministic synthetic weights/inputs keyed by tensor NAME (not by RNG call order), so the real
-reference (in make_golden.py), this oracle and the HIP product all get bit-identical parameters
-without shipping a 10 MB state_dict.  Test infrastructure (see oracle/__init__.py)."""
+"""Deterministic synthetic weights / inputs keyed by tensor NAME (not by RNG call order), so the real reference (in
+tests/golden/make_golden.py), the CPU oracle, the HIP product and bench.py all get bit-identical parameters without shipping a
+10 MB state_dict.  A neutral data generator: it imports neither the product (`edge-yolo_amd/`) nor the oracle (`oracle/`), and both
+sides of every parity test draw from it."""
 import zlib
 import numpy as np
 import torch

@@ -1,5 +1,5 @@
 """Golden-vector generator: runs the REAL reference (/root/reference, imported with the SURVEY.md
-Appendix C recipe) on synthetic weights/inputs from oracle/synth.py and stores inputs-by-seed +
+Appendix C recipe) on synthetic weights/inputs from synthdata.py and stores inputs-by-seed +
 expected outputs as small fixtures next to this file.  Runs only in the build container; the GPU box
 never has /root/reference and never runs this.  Usage: python tests/golden/make_golden.py
 """
@@ -18,7 +18,7 @@ tv = _ref_import.setup()
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from oracle import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 from oracle.nms import tv_nms  # noqa: E402
 
 # stand-in for the absent third-party torchvision.ops.nms (PARITY UNPINNED there, see oracle/nms.py)

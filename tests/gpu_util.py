@@ -2,7 +2,7 @@
 their reference-compatible state_dict keys) and into the CPU oracle."""
 import torch
 
-from oracle import synth
+import synthdata as synth
 
 # fp32 is the parity gate (north star: boxes/scores within 1e-3 in fp32).  fp16 is the throughput mode: storage is
 # half precision (11-bit mantissa), so activations carry ~1e-3 relative error per layer; tolerance documented here.

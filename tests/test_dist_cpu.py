@@ -75,3 +75,69 @@ def test_pack_unpack_roundtrip():
     rows = eyd.unpack_rows(eyd.pack_rows(b, c), 12)
     for i, r in enumerate(rows):
         assert torch.equal(r, b[i, : int(c[i])])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bench.py's real control flow (timed_steps: warm-up, barrier-bracketed timed region, gather of every step with `every` batches per
+# collective, flush of the partial final block inside the timed region; choose_variant: the start-up auto-tune) with a stub step.
+def _bench_worker(rank, world, port, steps, warmup, every, B, max_det, q):
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import contextlib
+    import bench
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        def reduce_max(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+
+        # start-up auto-tune: rank 1 sees variant "a" slower than "b", rank 0 the other way round; the max-reduced times decide, so
+        # both ranks must pick the same one
+        delays = {"a": (0.002, 0.030)[rank], "b": (0.012, 0.010)[rank]}
+        name, obj, times = bench.choose_variant({k: (lambda k=k: k) for k in ("a", "b")}, lambda k: (time.sleep(delays[k]), delays[k])[1], reduce_max)
+        gather = eyd.BoxGatherer(world, B, max_det, "cpu", own_stream=False, every=every)
+        blocks, n = [], [0]
+
+        def step():  # global step counter -> this rank's images of that step
+            k = n[0]
+            n[0] += 1
+            lo = (k * world + rank) * B
+            return _fake_results(lo, lo + B, max_det)
+
+        dt, _ = bench.timed_steps(step, lambda: None, gather, steps, warmup, contextlib.nullcontext, lambda: None, dist.barrier, reduce_max,
+                                  on_block=lambda k: blocks.append([r.numpy().copy() for r in gather.results(k)]))  # numpy: plain pickles through the queue
+        q.put((rank, name, obj, blocks, dt))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_control_flow_gloo_world2():
+    world, steps, warmup, every, B, max_det = 2, 7, 2, 3, 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, steps, warmup, every, B, max_det, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=180)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] == "b" and got[0][1] == "b"  # same winner on both ranks (max over ranks: a = 30 ms, b = 12 ms)
+    total = warmup + steps
+    full_b, full_c = _fake_results(0, total * world * B, max_det)
+    for rank in range(world):
+        blocks = got[rank][2]
+        # warm-up: 2 steps -> one partial block (flushed before the timed region); timed: 7 steps -> blocks of 3, 3 and a partial 1
+        assert [len(b) for b in blocks] == [2 * world * B, 3 * world * B, 3 * world * B, 1 * world * B]
+        rows = [r for b in blocks for r in b]
+        assert len(rows) == total * world * B  # every rank ends with all B*world*steps rows (+ warm-up), in global image order
+        for i, r in enumerate(rows):
+            assert torch.equal(torch.from_numpy(r), full_b[i, : int(full_c[i])]), f"rank {rank} image {i}"
+        assert got[rank][3] > 0

@@ -9,7 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import model as om, nms as onms, synth  # noqa: E402
+from oracle import model as om, nms as onms
+import synthdata as synth  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -187,7 +188,7 @@ def test_multi_stage_pipeline_matches_direct_execution():
     from edge_yolo_amd.engine.predictor import PipelinedRunner
     from edge_yolo_amd.nn.tasks import DetectionModel
     from edge_yolo_amd.utils import ops
-    from oracle import synth
+    import synthdata as synth
     m = DetectionModel("yolo11n-test.yaml")
     m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
     m = m.cuda().fuse().half().eval()
@@ -237,3 +238,51 @@ def test_predict_batches_matches_predict():
         ref = model.predict(x, conf=0.25, half=True)
         for a, b in zip(res, ref):
             assert torch.equal(a.boxes.data.cpu(), b.boxes.data.cpu())
+
+
+def test_predict_classes_and_agnostic_options(E):
+    """predict(classes=..., agnostic_nms=...) (reference cfg/default.yaml:51-65 -> ops.non_max_suppression, detect/predict.py:25-32):
+    the options reach the device NMS; rows bit-exact vs the oracle NMS with the same options on the same `pred`."""
+    model = E.YOLO("yolo11n-test.yaml")
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    x = synth.synth_images(2, 128, 128)
+    base = model.predict(x, conf=0.25, iou=0.7, device="cuda:0")
+    pred = model.predictor.runner(model.predictor.preprocess(x))[3].cpu().numpy()
+    for kw, okw in (({"classes": [0, 2, 5, 11]}, {"classes": [0, 2, 5, 11]}), ({"agnostic_nms": True}, {"agnostic": True}),
+                    ({"classes": [1, 3], "agnostic_nms": True, "max_det": 7}, {"classes": [1, 3], "agnostic": True, "max_det": 7})):
+        res = model.predict(x, conf=0.25, iou=0.7, device="cuda:0", **kw)
+        want = onms.non_max_suppression(pred, 0.25, 0.7, **okw)
+        for r, w in zip(res, want):
+            d = r.boxes.data.cpu().numpy()
+            w = w.copy()
+            w[:, :4] = np.clip(w[:, :4], 0, 128)  # tensor source: clip_boxes to the input shape (detect/predict.py:36-38 scale_boxes -> clip)
+            np.testing.assert_array_equal(d, w)
+            if "classes" in kw:
+                assert set(d[:, 5].astype(int).tolist()) <= set(kw["classes"])
+    assert sum(len(r) for r in base) > 0
+
+
+def test_save_load_predict_roundtrip(E, tmp_path):
+    """predict -> save -> YOLO(path) -> predict gives identical boxes (predict() folds BatchNorm in place; the checkpoint records it)."""
+    model = E.YOLO("yolo11n-test.yaml", nc=10)  # GC10-DET class count
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    x = synth.synth_images(2, 128, 160)
+    r1 = model.predict(x, conf=0.25, half=True, device="cuda:0")
+    f = str(tmp_path / "after_predict.pt")
+    model.save(f)
+    again = E.YOLO(f)
+    assert again.model.model[-1].nc == 10
+    r2 = again.predict(x, conf=0.25, half=True, device="cuda:0")
+    for a, b in zip(r1, r2):
+        assert torch.equal(a.boxes.data.cpu(), b.boxes.data.cpu()) and a.boxes.data.shape[0] > 0
+
+
+def test_wrong_current_device_is_an_error_not_a_fault(E):
+    """Kernels are launched on the CURRENT device's stream: an operand on another device must raise before any launch
+    (with one visible GPU the guard is exercised through the device index check itself)."""
+    from edge_yolo_amd import _lib as L
+    x = torch.zeros(1, 8, 4, 4, device="cuda:0")
+    L.require_device(x, "test")  # current device == operand device: fine
+    if torch.cuda.device_count() > 1:
+        with torch.cuda.device(1), pytest.raises(L.HipLibraryError):
+            L.require_device(x, "test")

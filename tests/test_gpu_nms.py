@@ -9,7 +9,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import nms as onms, synth  # noqa: E402
+from oracle import nms as onms
+import synthdata as synth  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -78,6 +79,33 @@ def test_multi_label_vs_oracle(ops, B, nc, A, conf, max_det):
     out = ops.non_max_suppression(pred.cuda(), conf, 0.7, multi_label=True, max_det=max_det)
     for a, b in zip(out, want):
         np.testing.assert_array_equal(a.cpu().numpy(), b)
+
+
+def test_heavy_bin_exhausted_subtree(ops):
+    """More than 4096 candidates share one top 12-bit score digit (scores in [0.5, 0.53125)) and overlap heavily, so the radix descent
+    opens that bin on its next digit, exhausts the subtree with far fewer than max_det boxes kept and climbs back to continue with the
+    lower bins (the path whose histogram reuse needed a barrier: ADVICE r1, head_nms.hip)."""
+    rng = np.random.default_rng(7)
+    A, nc, nheavy = 8192, 3, 5000
+    pred = np.zeros((2, 4 + nc, A), np.float32)
+    for b in range(2):
+        centres = rng.uniform(60, 580, (24, 2))
+        which = rng.integers(0, 24, nheavy)
+        pred[b, 0:2, :nheavy] = (centres[which] + rng.normal(0, 0.6, (nheavy, 2))).T  # 24 tight clusters: IoU > 0.7 inside a cluster
+        pred[b, 2:4, :nheavy] = 48.0
+        pred[b, 4, :nheavy] = rng.uniform(0.5, 0.53124, nheavy)
+        rest = A - nheavy
+        pred[b, 0:2, nheavy:] = rng.uniform(0, 640, (2, rest))
+        pred[b, 2:4, nheavy:] = rng.lognormal(np.log(20.0), 0.3, (2, rest))
+        pred[b, 4 + (b % nc), nheavy:] = rng.uniform(0.26, 0.49, rest)
+    for max_det in (300, 40):
+        want, widx = onms.non_max_suppression(pred, 0.25, 0.7, max_det=max_det, return_idx=True)
+        boxes, count, index = ops.nms_device(torch.tensor(pred).cuda(), 0.25, 0.7, max_det=max_det)
+        for b in range(2):
+            n = int(count[b])
+            assert n == want[b].shape[0] and (max_det == 40 or n > 24)
+            np.testing.assert_array_equal(index[b, :n].cpu().numpy(), widx[b])
+            np.testing.assert_array_equal(boxes[b, :n].cpu().numpy(), want[b])
 
 
 def test_argument_errors(ops):

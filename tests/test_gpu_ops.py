@@ -5,7 +5,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import model as om, synth  # noqa: E402
+from oracle import model as om
+import synthdata as synth  # noqa: E402
 from gpu_util import check, load_synth, to_dev  # noqa: E402
 
 DT = [torch.float32, torch.float16]

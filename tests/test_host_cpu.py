@@ -15,7 +15,8 @@ from edge_yolo_amd import _lib as L
 from edge_yolo_amd.nn import modules as M
 from edge_yolo_amd.nn.tasks import DetectionModel, guess_model_scale, guess_model_task, yaml_model_load
 from edge_yolo_amd.utils import ops as uops
-from oracle import model as om, synth
+from oracle import model as om
+import synthdata as synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -151,3 +152,54 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_save_load_roundtrip_unfused_and_fused(tmp_path):
+    """YOLO.save -> YOLO(path): tensor-only checkpoint, nc and the BN-folded ('fused') layout survive (predict() folds BatchNorm in
+    place, so a model saved after predict must come back with the folded conv weights AND biases, not with default BatchNorms)."""
+    y = edge_yolo_amd.YOLO("yolo11n-test.yaml", nc=10)
+    y.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in y.model.state_dict().items()}))
+    f1 = str(tmp_path / "unfused.pt")
+    y.save(f1)
+    ck = torch.load(f1, weights_only=True)  # the file is readable by the safe loader
+    assert ck["fused"] is False and ck["nc"] == 10
+    y1 = edge_yolo_amd.YOLO(f1)
+    a, b = y.model.state_dict(), y1.model.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a) and y1.model.model[-1].nc == 10
+    y.model.fuse()  # what predict() does
+    f2 = str(tmp_path / "fused.pt")
+    y.save(f2)
+    assert torch.load(f2, weights_only=True)["fused"] is True
+    y2 = edge_yolo_amd.YOLO(f2)
+    a, b = y.model.state_dict(), y2.model.state_dict()
+    assert y2.model.convs_folded() and set(a) == set(b) and all(torch.equal(a[k].float(), b[k].float()) for k in a)
+    # a checkpoint whose tensors do not cover the model is an error, not a silently half-initialised model
+    ck = torch.load(f2, weights_only=True)
+    ck["fused"] = False
+    torch.save(ck, f2)
+    with pytest.raises(ValueError, match="model tensors"):
+        edge_yolo_amd.YOLO(f2)
+
+
+def test_head_caches_follow_load_state_dict():
+    """Detect keeps packed tails / quality-head weights in plain dict caches: a load_state_dict must drop them."""
+    m = DetectionModel("yolo11n-test.yaml")
+    h = m.model[-1]
+    h._tails[123] = object()
+    h._qcache[(0, "cpu")] = object()
+    h._stride_f = [1.0]
+    m.load_state_dict(m.state_dict())
+    assert h._tails == {} and h._qcache == {} and h._stride_f is None
+
+
+def test_tunables_are_api_not_environment():
+    lib = L.lib()
+    assert lib.ey_tune_get(b"pw_m") == 110000
+    assert lib.ey_tune_set(b"pw_m", 5) == 0 and lib.ey_tune_get(b"pw_m") == 5
+    assert lib.ey_tune_set(b"pw_m", 110000) == 0
+    assert lib.ey_tune_set(b"no_such_knob", 1) != 0 and lib.ey_tune_get(b"no_such_knob") == -1
+    for d, _, files in os.walk(os.path.join(ROOT, "edge-yolo_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(d, f)).read()
+                assert "getenv" not in src and "os.environ" not in src, f"{f} reads the environment"

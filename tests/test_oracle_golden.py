@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import synth
+import synthdata as synth
 from oracle import model as om
 from oracle import nms as onms
 

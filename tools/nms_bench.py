@@ -7,7 +7,7 @@ import torch  # noqa: E402
 
 import edge_yolo_amd  # noqa: E402,F401
 from edge_yolo_amd.utils import ops  # noqa: E402
-from oracle import synth  # noqa: E402
+import synthdata as synth  # noqa: E402
 
 
 def t(pred, n=20, **kw):
