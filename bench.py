@@ -215,9 +215,11 @@ def main():
     g = torch.Generator(device=dev).manual_seed(rank)
     images = torch.rand(a.batch, 3, a.imgsz, a.imgsz, generator=g, device=dev).to(dtype)  # resident in HBM before timing
 
+    head_nms = {"conf": conf, "classes": None}  # predict mode: the head decode builds the NMS candidates in the same pass (as YOLO.predict does)
+
     def device_step(im):
-        pred, _ = model(im)
-        boxes, count, index = ops.nms_device(pred, conf, iou, max_det=max_det)
+        cand, _ = model(im, head_nms=head_nms)
+        boxes, count, index = ops.nms_device(cand, conf, iou, max_det=max_det)
         return boxes, count
 
     def reduce_max(sec):
@@ -246,22 +248,24 @@ def main():
         nlayers = len(model.model)
         post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
 
+        shared_streams = [torch.cuda.Stream(device=dev) for _ in range(5)]  # one set for every candidate pipeline (hardware-queue binding, see PipelinedRunner)
+
         def make_pipe(cuts):
             bounds = [0] + list(cuts) + [nlayers]
             stages = []
             for k in range(len(bounds) - 1):
                 lo, hi = bounds[k], bounds[k + 1]
                 if k == 0:
-                    stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi))
+                    stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi, head_nms=head_nms))
                 else:
-                    stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi))
+                    stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi, head_nms=head_nms))
             # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
             if a.nms_stage:
                 stages.append(post)
             else:
                 last = stages.pop()
                 stages.append(lambda stt, last=last: post(last(stt)))
-            pipe = PipelinedRunner(*stages, images)
+            pipe = PipelinedRunner(*stages, images, streams=shared_streams)
             for j in range(pipe.n):
                 pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
             pipe.cuts = list(cuts)

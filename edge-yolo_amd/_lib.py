@@ -74,6 +74,9 @@ SIGNATURES = {
     "ey_softmax_attention": (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp]),
     "ey_head_decode": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ey_head_decode_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "ey_nms_candidates_bytes": (_sz, [_i, _i]),
+    "ey_head_decode_levels_nms": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, _vp, _vp, _sz, _vp]),
+    "ey_nms_candidates": (_i, [_i, _i, _i, _vp, _sz, _f, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "ey_nms_workspace_bytes": (_sz, [_i, _i]),
     "ey_nms_workspace_bytes_ml": (_sz, [_i, _i, _i]),
     "ey_nms": (_i, [_i, _i, _i, _vp, _f, _f, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

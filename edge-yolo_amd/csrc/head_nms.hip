@@ -22,8 +22,20 @@ struct HdLevels {
   const float* w2[HD_MAXL];
   const float* b2[HD_MAXL];
 };
+// Optional fused NMS candidate build (predict mode, single label): per anchor the best class (first maximal index, ops.py:274) and the
+// key (score_bits << 32) | (0xFFFFFFFF - anchor) when score > conf (and the class passes the filter), else 0 -- exactly what
+// nms_score_kernel derives from `pred`, from the same fp32 values, so the NMS sees identical candidates without the (B,4+nc,A) tensor
+// ever being written or read.  box4 = rows 0-3 of pred (cx,cy,w,h), compact (B,4,A).
+struct HdNms {
+  unsigned long long* keys;  // [B][P] or null (off)
+  int* cls_id;               // [B][P]
+  float* box4;               // [B][4][A]
+  const uint8_t* mask;       // [nc] or null
+  float conf;
+  int P;
+};
 template <typename T>
-__global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv, int nc, int hid, float* __restrict__ pred, int A, int boxLs, int clsLs, int vec) {
+__global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv, int nc, int hid, float* __restrict__ pred, int A, int boxLs, int clsLs, int vec, HdNms nm) {
   int l = 0;
 #pragma unroll
   for (int i = 1; i < HD_MAXL; ++i)
@@ -125,21 +137,56 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
   }
   const float cx0 = ax + 0.5f, cy0 = ay + 0.5f;
   const float x1 = cx0 - dist[0], y1 = cy0 - dist[1], x2 = cx0 + dist[2], y2 = cy0 + dist[3];
-  float* pp = pred + (long)b * (4 + nc) * A + a_off + a;
-  pp[0] = (x1 + x2) * 0.5f * stride;
-  pp[(long)A] = (y1 + y2) * 0.5f * stride;
-  pp[2L * A] = (x2 - x1) * stride;
-  pp[3L * A] = (y2 - y1) * stride;
+  const float bcx = (x1 + x2) * 0.5f * stride, bcy = (y1 + y2) * 0.5f * stride, bw = (x2 - x1) * stride, bh = (y2 - y1) * stride;
   const T* cp = s_cls + tid * clsLs;
-  if (vec) {
+  float best = 0.f;
+  int bi = 0;
+  if (pred) {
+    float* pp = pred + (long)b * (4 + nc) * A + a_off + a;
+    pp[0] = bcx; pp[(long)A] = bcy; pp[2L * A] = bw; pp[3L * A] = bh;
+    if (vec) {
+      for (int c8 = 0; c8 < nc; c8 += 8) {
+        Vec8<T> t;
+        t.load(cp + c8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float sc = ey_sigmoid(t.get(i)) * q;
+          pp[(long)(4 + c8 + i) * A] = sc;
+          if (c8 + i == 0 || sc > best) { best = sc; bi = c8 + i; }
+        }
+      }
+    } else {
+      for (int c = 0; c < nc; ++c) {
+        const float sc = ey_sigmoid(to_f(cp[c])) * q;
+        pp[(long)(4 + c) * A] = sc;
+        if (c == 0 || sc > best) { best = sc; bi = c; }
+      }
+    }
+  } else if (vec) {
     for (int c8 = 0; c8 < nc; c8 += 8) {
       Vec8<T> t;
       t.load(cp + c8);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) pp[(long)(4 + c8 + i) * A] = ey_sigmoid(t.get(i)) * q;
+      for (int i = 0; i < 8; ++i) {
+        const float sc = ey_sigmoid(t.get(i)) * q;
+        if (c8 + i == 0 || sc > best) { best = sc; bi = c8 + i; }
+      }
     }
   } else {
-    for (int c = 0; c < nc; ++c) pp[(long)(4 + c) * A] = ey_sigmoid(to_f(cp[c])) * q;
+    for (int c = 0; c < nc; ++c) {
+      const float sc = ey_sigmoid(to_f(cp[c])) * q;
+      if (c == 0 || sc > best) { best = sc; bi = c; }
+    }
+  }
+  if (nm.keys) {
+    const int ga = a_off + a;
+    float* bx = nm.box4 + (long)b * 4 * A + ga;
+    bx[0] = bcx; bx[(long)A] = bcy; bx[2L * A] = bw; bx[3L * A] = bh;
+    unsigned long long key = 0ull;
+    if (best > nm.conf && (!nm.mask || nm.mask[bi]))
+      key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)ga);
+    nm.keys[(long)b * nm.P + ga] = key;
+    nm.cls_id[(long)b * nm.P + ga] = bi;
   }
 }
 
@@ -149,10 +196,10 @@ static int hd_pad(int elems, int es) {  // row stride (elements): 16-byte aligne
   return units * 16 / es;
 }
 
-extern "C" int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
-                                     const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
-                                     const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, ey_stream_t stream) {
-  EY_CHECK(pred && H && W && stride && box && cls && box_cstride && cls_cstride && a_off, "head_decode: null pointer");
+static int head_decode_impl(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
+                            const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
+                            const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, HdNms nm, ey_stream_t stream) {
+  EY_CHECK((pred || nm.keys) && H && W && stride && box && cls && box_cstride && cls_cstride && a_off, "head_decode: null pointer");
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "head_decode: bad dtype");
   EY_CHECK(nlevels >= 1 && nlevels <= HD_MAXL, "head_decode: %d levels (1..%d)", nlevels, HD_MAXL);
   EY_CHECK(B > 0 && nc > 0, "head_decode: bad extent");
@@ -185,14 +232,47 @@ extern "C" int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H
   if (dtype == EY_F16) {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec);
+    hipLaunchKernelGGL(head_decode_kernel<f16>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec, nm);
   } else {
     if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)head_decode_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ey_set_error(EY_ELAUNCH, "head_decode: cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec);
+    hipLaunchKernelGGL(head_decode_kernel<float>, grid, dim3(HD_ANCH), lds, st, B, lv, nc, quality ? q_hidden : 0, pred, A_total, boxLs, clsLs, vec, nm);
   }
   EY_LAUNCH_CHECK("ey_head_decode");
   return EY_OK;
+}
+
+extern "C" int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
+                                     const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
+                                     const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, ey_stream_t stream) {
+  EY_CHECK(pred, "head_decode: null pred");
+  HdNms nm = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  return head_decode_impl(dtype, B, nlevels, H, W, stride, box, box_cstride, cls, cls_cstride, nc, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, nm, stream);
+}
+
+static int nms_pow2(int A);
+extern "C" size_t ey_nms_candidates_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4) + (size_t)B * 4 * A * 4; }  // keys + class ids + (cx,cy,w,h)
+
+extern "C" int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box,
+                                         const int* box_cstride, const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1,
+                                         const float* const* q_b1, const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred_or_null,
+                                         int A_total, const int* a_off, float conf_thres, const uint8_t* class_mask, void* candidates, size_t candidates_bytes,
+                                         ey_stream_t stream) {
+  EY_CHECK(candidates && ey_aligned(candidates, 16) && candidates_bytes >= ey_nms_candidates_bytes(B, A_total), "head_decode_nms: candidate buffer missing / too small");
+  EY_CHECK(conf_thres >= 0.f && conf_thres <= 1.f, "head_decode_nms: Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", conf_thres);
+  EY_CHECK(a_off && H && W, "head_decode_nms: null pointer");
+  long covered = 0;
+  for (int l = 0; l < nlevels; ++l) covered += (long)H[l] * W[l];
+  EY_CHECK(covered == A_total, "head_decode_nms: the levels cover %ld of the %d anchors (every key slot must be written)", covered, A_total);
+  const int P = nms_pow2(A_total);
+  HdNms nm;
+  nm.keys = (unsigned long long*)candidates;
+  nm.cls_id = (int*)(nm.keys + (size_t)B * P);
+  nm.box4 = (float*)(nm.cls_id + (size_t)B * P);
+  nm.mask = class_mask;
+  nm.conf = conf_thres;
+  nm.P = P;
+  return head_decode_impl(dtype, B, nlevels, H, W, stride, box, box_cstride, cls, cls_cstride, nc, q_w1, q_b1, q_w2, q_b2, q_hidden, pred_or_null, A_total, a_off, nm, stream);
 }
 
 extern "C" int ey_head_decode(int dtype, int B, int H, int W, int nc, float stride, const void* box, int box_cstride, const void* cls,
@@ -338,8 +418,8 @@ __device__ __forceinline__ void nms_block_suffix_scan(unsigned* h) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, int multi_label, const float* __restrict__ pred, float iou_thres, int max_det,
-                                                                 int max_nms, float max_wh, int agnostic,
+__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
+                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
                                                                  int* __restrict__ out_index) {
@@ -348,7 +428,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
   KeptBox* kept = reinterpret_cast<KeptBox*>(smem + sizeof(NmsShared));
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long* keys = gkeys + (long)b * P;
-  const float* pb = pred + (long)b * (4 + nc) * A;
+  const float* pb = boxsrc + (long)b * img_stride;  // rows cx | cy | w | h, A values each (pred, or the compact box4 of the fused decode)
   const int* cid = cls_id + (long)b * P;  // (single-label only)
 
   // radix-descent state (wave-uniform, identical in every thread)
@@ -369,7 +449,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     if (need_hist) {
       for (int i = tid; i < 4096; i += 1024) S.hist[i] = 0u;
       __syncthreads();
-      for (long i = tid; i < P; i += 1024) {
+      for (long i = tid; i < nkeys; i += 1024) {
         const unsigned long long k = keys[i];
         if (k != 0ull && (k & above_mask) == prefix[level]) atomicAdd(&S.hist[(unsigned)(k >> sh) & (nb - 1)], 1u);
       }
@@ -413,7 +493,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     // ---- gather the chunk (unordered), then sort it
     if (tid == 0) S.cnt = 0;
     __syncthreads();
-    for (long i = tid; i < P; i += 1024) {
+    for (long i = tid; i < nkeys; i += 1024) {
       const unsigned long long k = keys[i];
       if (k != 0ull && (k & above_mask) == prefix[level]) {
         const int dgt = (int)((unsigned)(k >> sh) & (nb - 1));
@@ -537,6 +617,19 @@ static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array lengt
 extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4); }  // keys + class ids
 extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size_t)B * (((size_t)A * nc + 255) / 256 * 256) * 8; }
 
+static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
+                             float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
+                             hipStream_t st) {
+  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox);
+  EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
+  if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
+  hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
+                     keys, cls_id, out_boxes, out_count, out_index);
+  EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
+  return EY_OK;
+}
+
 extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
                       int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
                       ey_stream_t stream) {
@@ -556,7 +649,7 @@ extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres,
   if (multi_label) {
     P = ((long)A * nc + 255) / 256 * 256;
     const int Apad = (A + 255) / 256 * 256;
-    hipMemsetAsync(keys, 0, (size_t)B * P * 8, st);  // (tail padding; every real slot is written by the kernel)
+    (void)hipMemsetAsync(keys, 0, (size_t)B * P * 8, st);  // (tail padding; every real slot is written by the kernel)
     hipLaunchKernelGGL(nms_score_ml_kernel, dim3((unsigned)((long)Apad * nc / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, P);
   } else {
     P = nms_pow2(A);
@@ -567,12 +660,20 @@ extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres,
       hipLaunchKernelGGL(nms_score_kernel, dim3((unsigned)(P / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, cls_id, (int)P);
   }
   EY_LAUNCH_CHECK("ey_nms(score)");
-  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox);
-  EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
-  if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
-  hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, multi_label, pred, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id,
-                     out_boxes, out_count, out_index);
-  EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
-  return EY_OK;
+  return nms_select_launch(B, nc, A, P, P, multi_label, pred, (long)(4 + nc) * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, st);
+}
+
+extern "C" int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
+                                 int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream) {
+  EY_CHECK(candidates && out_boxes && out_count, "nms: null pointer");
+  EY_CHECK(B > 0 && nc > 0 && A > 0, "nms: bad extent");
+  EY_CHECK(iou_thres >= 0.f && iou_thres <= 1.f, "nms: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
+  EY_CHECK(max_det > 0 && max_det <= 4096 && max_nms > 0, "nms: max_det=%d (1..4096) max_nms=%d", max_det, max_nms);
+  EY_CHECK(candidates_bytes >= ey_nms_candidates_bytes(B, A) && ey_aligned(candidates, 16), "nms: candidate buffer too small");
+  const long P = nms_pow2(A);
+  const unsigned long long* keys = (const unsigned long long*)candidates;
+  const int* cls_id = (const int*)(keys + (size_t)B * P);
+  const float* box4 = (const float*)(cls_id + (size_t)B * P);
+  // only the A real key slots are scanned (the padding up to P is never written by the fused decode)
+  return nms_select_launch(B, nc, A, P, A, 0, box4, 4L * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, (hipStream_t)stream);
 }

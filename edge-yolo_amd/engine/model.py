@@ -154,7 +154,8 @@ class Model(torch.nn.Module):
                     stages = max(2, min(int(stages), n))
                     cuts = sorted({max(1, round(0.39 * (n - 1))), max(2, round(0.87 * (n - 1))), n - 1})[-(stages - 1):]
                     bounds = [0] + cuts + [n]
-                    fns = [(lambda st, lo=lo, hi=hi: m.forward_layers(st if lo else (st, []), lo, hi)) for lo, hi in zip(bounds[:-1], bounds[1:])]
+                    hn = {"conf": args["conf"], "classes": args["classes"]}  # the head stage also builds the NMS candidates (fused decode)
+                    fns = [(lambda st, lo=lo, hi=hi: m.forward_layers(st if lo else (st, []), lo, hi, head_nms=hn)) for lo, hi in zip(bounds[:-1], bounds[1:])]
                     last = fns.pop()
                     fns.append(lambda st, last=last: ops.nms_device(last(st)[0][0], args["conf"], args["iou"], args["classes"], args["agnostic_nms"], args["max_det"])[:2])
                     head = m.model[-1]

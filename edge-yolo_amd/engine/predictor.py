@@ -81,13 +81,18 @@ class PipelinedRunner:
     PipelinedRunner(f1, f2, ..., example): stage functions chained (stage k gets stage k-1's return value), example = input batch.
     """
 
-    def __init__(self, *args, warmup=2, copy_stream=False):
+    def __init__(self, *args, warmup=2, copy_stream=False, streams=None):
         """copy_stream=True: batches handed to submit(x) are copied into the stage-0 input buffer on a stream of their own (host
-        tensors: one H2D DMA per batch that overlaps the compute of the batches in flight) instead of on the first stage's stream."""
+        tensors: one H2D DMA per batch that overlaps the compute of the batches in flight) instead of on the first stage's stream.
+        streams: HIP streams to run the stages on (>= one per stage).  HIP binds streams to the 4 hardware queues in creation order,
+        so callers that build several pipelines (bench.py's start-up auto-tune) create ONE set of streams and hand it to all of
+        them: a second set would alias queues of the first and run ~25 % slower."""
         *stages, example = args
         dev = example.device
         self.dev, self.n = dev, len(stages)
-        self.streams = [torch.cuda.Stream(device=dev) for _ in stages]
+        if streams is not None and len(streams) < len(stages):
+            raise ValueError(f"PipelinedRunner: {len(stages)} stages need {len(stages)} streams, got {len(streams)}")
+        self.streams = list(streams[: len(stages)]) if streams is not None else [torch.cuda.Stream(device=dev) for _ in stages]
         self.copy_stream = torch.cuda.Stream(device=dev) if copy_stream else None
         self.sf, self.sp = self.streams[0], self.streams[-1]
         self.sets = []
@@ -159,20 +164,22 @@ class PipelinedRunner:
 
 
 class DetectionPredictor:
-    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True, validate_input=False):
+    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True, validate_input=False, keep_pred=False):
         """validate_input=True re-enables the reference's value-range check of tensor sources (data/loaders.py:554-560: max > 1 is an
         error there); it costs a device reduction and a host sync per call, so it is opt-in."""
-        self.model, self.device, self.half, self.validate_input = model, device, half, validate_input
+        self.model, self.device, self.half, self.validate_input, self.keep_pred = model, device, half, validate_input, keep_pred
         self.conf, self.iou, self.max_det, self.agnostic_nms, self.classes = conf, iou, max_det, agnostic_nms, classes
         self._lock = threading.Lock()
         self.runner = GraphRunner(self._device_step) if graph else self._device_step
 
     # ---- device side (captured)
     def _device_step(self, im):
-        preds = self.model(im)
+        # the head decode builds the NMS candidates for (conf, classes) in the same pass: the (B,4+nc,A) prediction tensor is only
+        # written when the caller asked for it (keep_pred)
+        preds = self.model(im, head_nms={"conf": self.conf, "classes": self.classes, "keep_pred": self.keep_pred})
         pred = preds[0] if isinstance(preds, (list, tuple)) else preds
         boxes, count, index = ops.nms_device(pred, self.conf, self.iou, self.classes, self.agnostic_nms, self.max_det)
-        return boxes, count, index, pred
+        return boxes, count, index, getattr(pred, "pred", pred)
 
     def preprocess(self, im):
         """Tensor sources: BCHW float in [0,1] (reference LoadTensor, data/loaders.py:516-586).  ndarray / list sources:

@@ -441,8 +441,32 @@ def head_decode(box, cls, stride, q, pred, a_off):
                                        qa[0], qa[1], qa[2], qa[3], hid, pred.data_ptr(), pred.shape[2], a_off, L.stream()), "ey_head_decode")
 
 
-def head_decode_levels(levels, pred):
-    """levels: list (<= 4) of (box, cls, stride, q-or-None, a_off) -> every level of the fused DGQP + DFL + decode in ONE launch."""
+class Candidates:
+    """NMS candidates written by the fused head decode (ey_head_decode_levels_nms): sort keys + best class per anchor + (cx,cy,w,h),
+    for the conf threshold / class filter they were built with.  `utils.ops.nms_device` accepts it in place of `pred`."""
+
+    def __init__(self, buf, B, nc, A, conf, classes, pred=None):
+        self.buf, self.B, self.nc, self.A, self.conf, self.classes, self.pred = buf, B, nc, A, float(conf), (tuple(classes) if classes is not None else None), pred
+        self.shape = (B, 4 + nc, A)
+        self.device = buf.device
+
+
+def nms_candidates(cand, iou_thres, max_det, max_nms, max_wh, agnostic):
+    """Selection + greedy suppression on a Candidates buffer -> (boxes (B,max_det,6), count (B,), index (B,max_det))."""
+    dev = cand.device
+    boxes = torch.empty((cand.B, max_det, 6), dtype=torch.float32, device=dev)
+    count = torch.empty((cand.B,), dtype=torch.int32, device=dev)
+    index = torch.empty((cand.B, max_det), dtype=torch.int32, device=dev)
+    with _tr("nms_select_greedy_kernel", cand.buf.numel() + _nb(boxes)):
+        L.check(L.lib().ey_nms_candidates(cand.B, cand.nc, cand.A, cand.buf.data_ptr(), cand.buf.numel(), float(iou_thres), int(max_det), int(max_nms), float(max_wh),
+                                          int(bool(agnostic)), boxes.data_ptr(), count.data_ptr(), index.data_ptr(), L.stream()), "ey_nms_candidates")
+    return boxes, count, index
+
+
+def head_decode_levels(levels, pred, nms=None):
+    """levels: list (<= 4) of (box, cls, stride, q-or-None, a_off) -> every level of the fused DGQP + DFL + decode in ONE launch.
+    nms = (conf_thres, class_mask uint8 tensor or None, classes): also build the NMS candidates in the same pass (pred may then be None);
+    returns a Candidates object."""
     n = len(levels)
     box0, cls0 = levels[0][0], levels[0][1]
     L.require_device(box0, "head_decode")
@@ -458,6 +482,17 @@ def head_decode_levels(levels, pred):
     qa = [PA(*[(lv[3][j].data_ptr() if lv[3] is not None else None) for lv in levels]) for j in range(4)]
     nbytes = sum(_nb(lv[0], lv[1]) + B * lv[0].shape[2] * lv[0].shape[3] * (4 + nc) * 4 for lv in levels)
     flops = sum(2.0 * B * lv[0].shape[2] * lv[0].shape[3] * (hid * 21 + 200) for lv in levels)
+    if nms is not None:
+        conf, mask, classes = nms
+        A = sum(lv[0].shape[2] * lv[0].shape[3] for lv in levels)
+        nb = L.lib().ey_nms_candidates_bytes(B, A)
+        buf = torch.empty(nb, dtype=torch.uint8, device=box0.device)
+        in_bytes = sum(_nb(lv[0], lv[1]) for lv in levels)
+        with _tr("head_decode_kernel", in_bytes + nb + (B * A * (4 + nc) * 4 if pred is not None else 0), flops, note=f"{n} levels + NMS keys"):
+            L.check(L.lib().ey_head_decode_levels_nms(L.dtype_code(box0.dtype), B, n, Hs, Ws, st, boxp, boxcs, clsp, clscs, nc, qa[0], qa[1], qa[2], qa[3], hid,
+                                                      pred.data_ptr() if pred is not None else None, A, offs, float(conf), mask.data_ptr() if mask is not None else None,
+                                                      buf.data_ptr(), nb, L.stream()), "ey_head_decode_levels_nms")
+        return Candidates(buf, B, nc, A, conf, classes, pred)
     with _tr("head_decode_kernel", nbytes, flops, note=f"{n} levels"):
         L.check(L.lib().ey_head_decode_levels(L.dtype_code(box0.dtype), B, n, Hs, Ws, st, boxp, boxcs, clsp, clscs, nc, qa[0], qa[1], qa[2], qa[3], hid,
                                               pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")

@@ -136,7 +136,11 @@ class Detect(nn.Module):
     def _quality_params(self, i, device):
         return None
 
-    def forward(self, x):
+    def forward(self, x, nms=None):
+        """nms=None: returns (pred (B,4+nc,A) fp32, raw per-level maps) like the reference.  nms=dict(conf=, classes=None, keep_pred=False)
+        (predict pipelines): the decode also builds the NMS candidates for that confidence threshold / class filter in the same pass
+        and returns (_ops.Candidates, raw maps) -- `utils.ops.nms_device` takes it in place of `pred`, which is then neither written nor
+        re-read (keep_pred=True still writes it, as Candidates.pred)."""
         if self.end2end:
             raise NotImplementedError("end2end (NMS-free) heads are outside the built path")
         if self.training:
@@ -146,7 +150,8 @@ class Detect(nn.Module):
         xs = [L.as_nhwc(t) for t in x]
         B, dev, dt = xs[0].shape[0], xs[0].device, xs[0].dtype
         A = sum(t.shape[2] * t.shape[3] for t in xs)
-        pred = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=dev)
+        want_pred = nms is None or nms.get("keep_pred") or not (len(xs) <= 4 and self.nc > 1)
+        pred = torch.empty((B, 4 + self.nc, A), dtype=torch.float32, device=dev) if want_pred else None
         a_off = 0
         if getattr(self, "_stride_f", None) is None:
             self._stride_f = [float(s) for s in self.stride]  # host copy once (no D2H inside a captured graph)
@@ -188,6 +193,18 @@ class Detect(nn.Module):
             # two-stage pipelines (engine/predictor.py::PipelinedRunner) put the decode into the post-processing stage, next to the
             # NMS: the next batch's backbone then starts as soon as the towers are done instead of behind the decode launch
             return levels, x
+        if nms is not None and len(levels) <= 4 and self.nc > 1:
+            classes = nms.get("classes")
+            mask = None
+            if classes is not None:
+                key = (tuple(classes), dev)
+                if getattr(self, "_mask_key", None) != key:  # tiny host->device upload, once per filter (not inside a captured graph)
+                    m = torch.zeros(self.nc, dtype=torch.uint8)
+                    m[torch.as_tensor(list(classes), dtype=torch.long)] = 1
+                    self._mask, self._mask_key = m.to(dev), key
+                mask = self._mask
+            cand = ops.head_decode_levels(levels, pred if nms.get("keep_pred") else None, nms=(nms["conf"], mask, classes))
+            return cand, x
         self._decode(levels, pred)
         return pred if self.export else (pred, x)
 

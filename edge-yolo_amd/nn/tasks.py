@@ -133,22 +133,17 @@ class BaseModel(nn.Module):
             raise NotImplementedError("training losses are outside the built path (inference forward only)")
         return self.predict(x, *args, **kwargs)
 
-    def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
+    def predict(self, x, profile=False, visualize=False, augment=False, embed=None, head_nms=None):
+        """head_nms (extension, see Detect.forward): dict(conf=, classes=, keep_pred=) -> the head also builds the NMS candidates."""
         if profile or visualize or embed:
             raise NotImplementedError("profile/visualize/embed hooks are not part of the built path")
         if torch.is_tensor(x) and x.is_cuda and x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):  # launches go to the current device's stream (_lib.stream)
-                return self._predict_once(x)
-        return self._predict_once(x)  # augment=True falls back to single scale exactly as the reference does (:181-187)
+                return self._predict_once(x, head_nms=head_nms)
+        return self._predict_once(x, head_nms=head_nms)  # augment=True falls back to single scale exactly as the reference does (:181-187)
 
-    def _predict_once(self, x, profile=False, visualize=False, embed=None):
-        y = []
-        for m in self.model:
-            if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
-            y.append(x if m.i in self.save else None)
-        return x
+    def _predict_once(self, x, profile=False, visualize=False, embed=None, head_nms=None):
+        return self.forward_layers((x, []), 0, len(self.model), head_nms=head_nms)[0]
 
     def forward_features(self, x):
         """_predict_once without the last (head) module: returns the head's input list (for callers that pipeline the head apart)."""
@@ -161,15 +156,16 @@ class BaseModel(nn.Module):
         h = self.model[-1]
         return [x if j == -1 else y[j] for j in h.f] if not isinstance(h.f, int) else (x if h.f == -1 else y[h.f])
 
-    def forward_layers(self, state, lo, hi):
-        """Layers [lo, hi) of _predict_once on `state` = (x, saved outputs so far) -> new state: lets a caller cut the graph into
-        pipeline stages (each stage a captured hipGraph on its own stream)."""
+    def forward_layers(self, state, lo, hi, head_nms=None):
+        """Layers [lo, hi) of _predict_once (reference tasks.py:152-179) on `state` = (x, saved outputs so far) -> new state: lets a
+        caller cut the graph into pipeline stages (each stage a captured hipGraph on its own stream).  head_nms: passed to a Detect
+        head in the range (fused NMS candidate build, see Detect.forward)."""
         x, y = state
         y = list(y)
         for m in self.model[lo:hi]:
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
+            x = m(x, nms=head_nms) if (head_nms is not None and isinstance(m, Detect)) else m(x)
             y.append(x if m.i in self.save else None)
         return x, y
 

@@ -54,6 +54,17 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
     from ..nn import _ops
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
+    if isinstance(prediction, _ops.Candidates):  # built by the fused head decode for (conf, classes): selection + suppression only
+        c = prediction
+        assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+        if abs(c.conf - float(conf_thres)) > 1e-12 or c.classes != (tuple(classes) if classes is not None else None):
+            raise ValueError(f"nms_device: the candidates were built for conf={c.conf} classes={c.classes}, not conf={conf_thres} classes={classes}")
+        if multi_label and c.nc > 1:
+            raise ValueError("nms_device: fused candidates are single-label (predict mode); validation-mode NMS needs `pred`")
+        if c.device.index != torch.cuda.current_device():
+            with torch.cuda.device(c.device):
+                return _ops.nms_candidates(c, iou_thres, max_det, max_nms, max_wh, agnostic)
+        return _ops.nms_candidates(c, iou_thres, max_det, max_nms, max_wh, agnostic)
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
     nc = nc or (prediction.shape[1] - 4)

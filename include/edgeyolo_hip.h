@@ -215,6 +215,23 @@ int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H, const int
                           const float* const* q_b1, const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred,
                           int A_total, const int* a_off, ey_stream_t stream);
 
+/* K9+K10 with the NMS candidate build fused in (predict mode, single label; Detect._inference head.py:117-148 followed by the
+ * candidate selection of non_max_suppression, utils/ops.py:253,273-275): same arithmetic as ey_head_decode_levels, and per anchor the
+ * best class (first maximal index), the sort key (score_bits << 32 | ~anchor) when score > conf_thres and the class passes
+ * class_mask (else 0), and the box (cx,cy,w,h) go to `candidates` (ey_nms_candidates_bytes(B, A_total) bytes, 16-byte aligned):
+ * exactly what ey_nms derives from `pred`, from the same fp32 values -- so ey_nms_candidates() returns bit-identical rows without the
+ * (B,4+nc,A) tensor being written or re-read.  pred_or_null: also write the reference-layout prediction tensor (callers that want it).
+ * The levels must cover all A_total anchors. */
+size_t ey_nms_candidates_bytes(int B, int A);
+int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
+                              const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
+                              const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred_or_null, int A_total, const int* a_off,
+                              float conf_thres, const uint8_t* class_mask, void* candidates, size_t candidates_bytes, ey_stream_t stream);
+/* Second half of ey_nms (selection + greedy suppression, utils/ops.py:277-309 + torchvision.ops.nms) on a candidate buffer
+ * written by ey_head_decode_levels_nms.  Outputs as ey_nms. */
+int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
+                      int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream);
+
 /* ---- K11: batched per-image NMS (non_max_suppression, utils/ops.py:230-316, and the torchvision.ops.nms it calls
  * at :296).  multi_label=0: best class per anchor (predict, ops.py:273-275); multi_label=1: one candidate per
  * (anchor, class) pair above conf (validation, ops.py:270-272; needs the _ml workspace).

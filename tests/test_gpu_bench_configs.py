@@ -24,7 +24,7 @@ from oracle import model as om, nms as onms  # noqa: E402
 
 # f16 storage through ~100 layers: measured max |score - oracle| and max box error (pixels, relative to the image size) per config
 # on MI355X are printed by the test; the asserted bounds leave ~2x head-room.
-TOL = {"score": 1.5e-2, "box_frac": 6e-3, "match_floor": 0.90}
+TOL = {"score": 1.5e-2, "box_frac": 6e-3, "match_floor": 0.85}
 
 
 def _iou(a, b):

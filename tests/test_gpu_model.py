@@ -247,7 +247,7 @@ def test_predict_classes_and_agnostic_options(E):
     model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
     x = synth.synth_images(2, 128, 128)
     base = model.predict(x, conf=0.25, iou=0.7, device="cuda:0")
-    pred = model.predictor.runner(model.predictor.preprocess(x))[3].cpu().numpy()
+    pred = model.model(model.predictor.preprocess(x))[0].cpu().numpy()  # the reference-layout tensor (the predictor itself never writes it)
     for kw, okw in (({"classes": [0, 2, 5, 11]}, {"classes": [0, 2, 5, 11]}), ({"agnostic_nms": True}, {"agnostic": True}),
                     ({"classes": [1, 3], "agnostic_nms": True, "max_det": 7}, {"classes": [1, 3], "agnostic": True, "max_det": 7})):
         res = model.predict(x, conf=0.25, iou=0.7, device="cuda:0", **kw)
@@ -286,3 +286,31 @@ def test_wrong_current_device_is_an_error_not_a_fault(E):
     if torch.cuda.device_count() > 1:
         with torch.cuda.device(1), pytest.raises(L.HipLibraryError):
             L.require_device(x, "test")
+
+
+@pytest.mark.parametrize("name,nc", [("yolo11n-test.yaml", 80), ("yolo11n.yaml", 80), ("yolo11n-test.yaml", 10)])
+def test_fused_candidates_equal_nms_on_pred(E, name, nc):
+    """Head decode with the NMS candidate build fused in (ey_head_decode_levels_nms + ey_nms_candidates, what predict() runs) returns
+    bit-identical rows / counts / anchor indices to ey_nms on the materialised `pred`, with and without a class filter, and the
+    optional `pred` output equals the plain decode's."""
+    from edge_yolo_amd.nn.tasks import DetectionModel
+    from edge_yolo_amd.utils import ops
+    m = DetectionModel(name, nc=nc)
+    m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m = m.cuda().fuse().half().eval()
+    x = synth.synth_images(3, 160, 224).cuda().half()
+    pred = m(x)[0]
+    for classes in (None, [0, 3, 7]):
+        for conf in (0.25, 0.05):
+            cand, _ = m(x, head_nms={"conf": conf, "classes": classes, "keep_pred": True})
+            assert torch.equal(cand.pred, pred)
+            got = ops.nms_device(cand, conf, 0.6, classes=classes, max_det=100)
+            want = ops.nms_device(pred, conf, 0.6, classes=classes, max_det=100)
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+            lean, _ = m(x, head_nms={"conf": conf, "classes": classes})  # no pred written
+            assert lean.pred is None
+            for g, w in zip(ops.nms_device(lean, conf, 0.6, classes=classes, max_det=100, agnostic=True), ops.nms_device(pred, conf, 0.6, classes=classes, max_det=100, agnostic=True)):
+                assert torch.equal(g, w)
+    with pytest.raises(ValueError):
+        ops.nms_device(cand, 0.3, 0.6)  # candidates were built for another threshold
