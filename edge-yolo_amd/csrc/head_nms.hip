@@ -401,25 +401,54 @@ struct NmsShared {
 };
 
 __device__ __forceinline__ void nms_block_suffix_scan(unsigned* h) {
-  // in place: h[b] <- sum_{b' >= b} h[b'] for 4096 bins, 1024 threads (4 bins each), Hillis-Steele over thread partials
-  __shared__ unsigned part[1024];
-  const int t = threadIdx.x;
-  unsigned v3 = h[4 * t + 3], v2 = h[4 * t + 2] + v3, v1 = h[4 * t + 1] + v2, v0 = h[4 * t] + v1;
-  part[t] = v0;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    unsigned add = (t + off < 1024) ? part[t + off] : 0u;
-    __syncthreads();
-    part[t] += add;
-    __syncthreads();
+  // in place: h[b] <- sum_{b' >= b} h[b'] for 4096 bins, 1024 threads (4 bins each): per-thread suffix, wave-level suffix scan of the
+  // thread totals by lane shuffles (no barrier), then the 16 wave totals through LDS -- 2 barriers in all
+  __shared__ unsigned wtot[16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned v3 = h[4 * t + 3], v2 = h[4 * t + 2] + v3, v1 = h[4 * t + 1] + v2, v0 = h[4 * t] + v1;
+  unsigned run = v0;  // inclusive suffix sum over lanes >= lane
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_down(run, off, 64);
+    if (lane + off < 64) run += o;
   }
-  const unsigned above = (t + 1 < 1024) ? part[t + 1] : 0u;
+  if (lane == 0) wtot[wave] = run;
+  __syncthreads();
+  unsigned above = run - v0;  // lanes above mine in this wave
+  for (int w = wave + 1; w < 16; ++w) above += wtot[w];
   h[4 * t] = v0 + above; h[4 * t + 1] = v1 + above; h[4 * t + 2] = v2 + above; h[4 * t + 3] = v3 + above;
   __syncthreads();
 }
 
+// Descending bitonic sort of 1024 keys, one per thread: the 45 compare-exchange steps with partner distance < 64 run on lane shuffles
+// inside the wave (no barrier, no LDS), only the 10 steps with distance >= 64 go through LDS.  Keys are unique (or 0 = padding), so
+// the result does not depend on the network.
+__device__ __forceinline__ unsigned long long nms_sort1024(unsigned long long key, unsigned long long* xch) {
+  const int t = threadIdx.x;
+#pragma unroll 1
+  for (int k = 2; k <= 1024; k <<= 1) {
+    const bool desc = (t & k) == 0;
+#pragma unroll 1
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long other;
+      if (j >= 64) {
+        xch[t] = key;
+        __syncthreads();
+        other = xch[t ^ j];
+        __syncthreads();
+      } else {
+        const unsigned lo = __shfl_xor((unsigned)key, j, 64), hi = __shfl_xor((unsigned)(key >> 32), j, 64);
+        other = ((unsigned long long)hi << 32) | lo;
+      }
+      const bool keep_max = desc == ((t & j) == 0);
+      key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
+    }
+  }
+  return key;
+}
+
 __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
-                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
                                                                  int* __restrict__ out_index) {
@@ -470,13 +499,19 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     // lowest-cost chunk: the largest bin_lo < H whose digit range [bin_lo, H) holds >= NMS_TARGET keys (else 0)
     if (tid == 0) S.sel_lo = 0;
     __syncthreads();
-    for (int bin = tid; bin < H; bin += 1024)
-      if (S.hist[bin] - s_hi >= (unsigned)NMS_TARGET) atomicMax(&S.sel_lo, bin);
+    {
+      int best = 0;  // bins are visited in increasing order: the last qualifying one is this thread's largest
+      for (int bin = tid; bin < H; bin += 1024)
+        if (S.hist[bin] - s_hi >= (unsigned)target) best = bin;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+      if (lane == 0 && best > 0) atomicMax(&S.sel_lo, best);  // one LDS atomic per wave
+    }
     __syncthreads();
     int lo = S.sel_lo;
     unsigned cnt = S.hist[lo] - s_hi;
-    if (cnt > (unsigned)NMS_CAP) {
-      ++lo;  // drop the heavy lowest bin: what is left has < NMS_TARGET keys
+    if (cnt > (unsigned)cap) {
+      ++lo;  // drop the heavy lowest bin: what is left has < target keys
       cnt = lo < H ? S.hist[lo] - s_hi : 0u;
       if (cnt == 0u) {  // the top remaining bin alone exceeds the cap: open it on its next digit
         const int heavy = lo - 1;
@@ -502,19 +537,26 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     }
     __syncthreads();
     int n = (int)cnt;
-    int n2 = 64;
-    while (n2 < n) n2 <<= 1;
-    for (int i = n + tid; i < n2; i += 1024) S.chunk[i] = 0ull;
-    __syncthreads();
-    for (int k = 2; k <= n2; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < (n2 >> 1); t += 1024) {
-          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
-          const unsigned long long u = S.chunk[i], v = S.chunk[ixj];
-          const bool desc = (i & k) == 0;
-          if (desc ? (u < v) : (u > v)) { S.chunk[i] = v; S.chunk[ixj] = u; }
+    if (n <= 1024) {  // (predict mode: cap = 1024) one key per thread, register sort
+      const unsigned long long sorted = nms_sort1024(tid < n ? S.chunk[tid] : 0ull, S.chunk + 1024);
+      __syncthreads();
+      S.chunk[tid] = sorted;
+      __syncthreads();
+    } else {
+      int n2 = 64;
+      while (n2 < n) n2 <<= 1;
+      for (int i = n + tid; i < n2; i += 1024) S.chunk[i] = 0ull;
+      __syncthreads();
+      for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int t = tid; t < (n2 >> 1); t += 1024) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+            const unsigned long long u = S.chunk[i], v = S.chunk[ixj];
+            const bool desc = (i & k) == 0;
+            if (desc ? (u < v) : (u > v)) { S.chunk[i] = v; S.chunk[ixj] = u; }
+          }
+          __syncthreads();
         }
-        __syncthreads();
       }
     }
     if (S.processed + n > max_nms) n = max_nms - S.processed;  // ops.py:285-286 cap
@@ -617,6 +659,9 @@ static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array lengt
 extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4); }  // keys + class ids
 extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size_t)B * (((size_t)A * nc + 255) / 256 * 256) * 8; }
 
+// chunk size of the radix selection: [target, cap] candidates per round.  predict mode needs ~max_det survivors, so small chunks (one key
+// per thread, register sort) are cheapest; validation mode (multi_label: up to max_nms = 30000 candidates) amortises each pass over the
+// A*nc keys with the largest chunk the LDS sort takes.
 static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
                              float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
                              hipStream_t st) {
@@ -624,8 +669,9 @@ static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi
   EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
+  const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
   hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
-                     keys, cls_id, out_boxes, out_count, out_index);
+                     target, cap, keys, cls_id, out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }
