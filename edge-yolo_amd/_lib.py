@@ -39,6 +39,23 @@ class ConvDirectDesc(C.Structure):
     ]
 
 
+class BlockStage(C.Structure):
+    """ey_block_stage (include/edgeyolo_hip.h): one stage of a block program."""
+    _fields_ = [
+        ("op", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+        ("k", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32), ("nsrc", C.c_int32),
+        ("src", C.c_int64 * 2), ("src_ext", C.c_int32 * 2), ("src_img", C.c_int64 * 2), ("src_cs", C.c_int32 * 2), ("src_C", C.c_int32 * 2),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("w_g", C.c_int64), ("w_gmax", C.c_int32),
+        ("y", C.c_int64), ("y_ext", C.c_int32), ("y_img", C.c_int64), ("y_cs", C.c_int32), ("Cout", C.c_int32),
+        ("has_res", C.c_int32), ("res", C.c_int64), ("res_ext", C.c_int32), ("res_img", C.c_int64), ("res_cs", C.c_int32),
+        ("has_addz", C.c_int32), ("addz", C.c_int64), ("addz_ext", C.c_int32), ("addz_img", C.c_int64), ("addz_cs", C.c_int32), ("addz_H", C.c_int32),
+        ("addz_W", C.c_int32), ("out_scale", C.c_float),
+        ("ngroup", C.c_int32), ("src_g", C.c_int64), ("y_g", C.c_int64), ("heads", C.c_int32),
+        ("kpad", C.c_int32), ("nt_pack", C.c_int32), ("mt", C.c_int32), ("nti", C.c_int32), ("zsy", C.c_float), ("zsx", C.c_float),
+    ]
+
+
+BLK_CONV, BLK_DW, BLK_DWT, BLK_POOL, BLK_LINATTN = range(5)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes): every symbol include/edgeyolo_hip.h declares
 SIGNATURES = {
@@ -74,6 +91,10 @@ SIGNATURES = {
     "ey_softmax_attention": (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp]),
     "ey_head_decode": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ey_head_decode_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "ey_block_stage_sizeof": (_sz, []),
+    "ey_block_program_bytes": (_sz, [_i]),
+    "ey_block_compile": (_i, [C.POINTER(BlockStage), _i, _vp, _sz]),
+    "ey_block_run": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p), _i, _vp]),
     "ey_nms_candidates_bytes": (_sz, [_i, _i]),
     "ey_head_decode_levels_nms": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, _vp, _vp, _sz, _vp]),
     "ey_nms_candidates": (_i, [_i, _i, _i, _vp, _sz, _f, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
@@ -99,7 +120,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.ey_abi_sizeof(0) != C.sizeof(ConvDesc) or L.ey_abi_sizeof(1) != C.sizeof(ConvDirectDesc):
+        if L.ey_abi_sizeof(0) != C.sizeof(ConvDesc) or L.ey_abi_sizeof(1) != C.sizeof(ConvDirectDesc) or L.ey_block_stage_sizeof() != C.sizeof(BlockStage):
             raise HipLibraryError(f"{LIB_PATH}: struct layout differs from this binding (stale build?): rebuild with make -C csrc")
         _lib = L
     return _lib
@@ -165,6 +186,8 @@ def as_nhwc(x):
         raise ValueError(f"expected a BCHW tensor, got shape {tuple(x.shape)}")
     if is_nhwc_view(x):
         return x
+    from .nn import _ops
+    _ops._no_block("layout conversion")  # (a block program is being recorded: the chain must stay NHWC)
     B, Cc, H, W = x.shape
     y = empty_nhwc(B, Cc, H, W, x.dtype, x.device)
     if x.is_contiguous():

@@ -1,0 +1,443 @@
+// Block programs: a whole chain of layers on SMALL feature maps (20x20 at 640x640) as ONE launch.
+//
+// At batch 32 the 20x20 part of the network (stride-2 conv -> DSC3K2_Wavelet -> SPPF -> C2PSA_LinearAttention, the last neck
+// block, the 20x20 head towers) is ~45 launches of 5-20 us that each move 1-6 MB: pure launch / ramp-up / tail latency.  Here ONE
+// persistent 1024-thread workgroup per image walks a "program" of stages (conv 1x1/3x3 with the full ey_conv2d epilogue, depthwise
+// kxk, Haar DWT, the SPPF pool chain, MFMA linear attention) with a workgroup barrier between stages.  Activations go through
+// global memory (they stay in L2: 20x20x256 f16 = 200 KB per image), weights stream from L2, nothing returns to the host between
+// layers; 32 images occupy 32 CUs and leave the other 224 to the pipeline stages that run beside it (large-map, HBM-bound layers).
+//
+// Same arithmetic as the stand-alone kernels: f16 storage between stages (the reference's intermediate tensors), fp32
+// accumulation (v_mfma_f32_16x16x32_f16), fp32 epilogues; the K order of every contraction is (ky, kx, source, channel) like
+// ey_conv2d.  f16 only (the fp32 parity mode keeps the per-layer kernels).
+#include "common.h"
+#include "linattn_mfma.inc.h"
+
+#define BLK_THREADS 1024
+#define BLK_WAVES 16
+#define BLK_LDS_BYTES (104 * 1024)
+#define BLK_MAX_EXT 8
+
+typedef ey_block_stage BlkStage;
+struct BlkExt { char* p[BLK_MAX_EXT]; };
+
+__device__ __forceinline__ void load4(const f16* p, float (&o)[4]) {
+  const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (float)v[j];
+}
+__device__ __forceinline__ void store4(f16* p, const float* v) {
+  const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  *reinterpret_cast<f16x4*>(p) = o;
+}
+__device__ __forceinline__ const f16* blk_ptr(const BlkExt& e, int64_t addr, int ext) {
+  return reinterpret_cast<const f16*>(ext >= 0 ? e.p[ext] + addr : reinterpret_cast<char*>(addr));
+}
+
+// ---------------------------------------------------------------------------------------------------------------- conv
+// Work item = (group, MT pixel tiles of 16, NTI of the NT 16-channel MFMA row blocks of one packed block tile); the 16 waves walk
+// the items round-robin, consecutive waves share a pixel tile (its fragments hit in L1).  A = packed weights (row permutation of
+// ey_conv_pack_weight: lane (r, g) ends up with 4*NTI CONSECUTIVE channels of pixel r), B = pixels by range-checked buffer loads
+// (padding taps, pixel tails and channel tails read zeros).
+template <int MT, int NTI>
+__device__ void blk_conv(const BlkStage& s, const BlkExt& ext, int b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int M = s.Ho * s.Wo, NT = s.nt_pack, BN = 16 * NT;
+  const int mtiles = (M + 16 * MT - 1) / (16 * MT);
+  const int nsub = NT / NTI, nblk = (s.Cout + BN - 1) / BN;
+  const int per_tile = nblk * nsub;
+  const int nitems = s.ngroup * mtiles * per_tile;
+  const int pad = s.k >> 1;
+  for (int it = wave; it < nitems; it += BLK_WAVES) {
+    const int sub = it % nsub;
+    int t = it / nsub;
+    const int nb = t % nblk;
+    t /= nblk;
+    const int mt_i = t % mtiles, grp = t / mtiles;
+    const int wset = min(grp, s.w_gmax);
+    // ---- operands
+    __amdgpu_buffer_rsrc_t rs[2];
+#pragma unroll
+    for (int si = 0; si < 2; ++si) {
+      const int sj = si < s.nsrc ? si : 0;
+      const f16* base = blk_ptr(ext, s.src[sj], s.src_ext[sj]) + (long)b * s.src_img[sj] + (si == 0 ? (long)grp * s.src_g : 0L);
+      rs[si] = ey_rsrc(base, (unsigned)((((long)s.H * s.W - 1) * s.src_cs[sj] + s.src_C[sj]) * 2));
+    }
+    const f16* wbase = reinterpret_cast<const f16*>(s.w) + (long)wset * s.w_g;
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(wbase, (unsigned)((long)nblk * BN * s.kpad * 2));
+    unsigned woff[NTI];
+#pragma unroll
+    for (int nt = 0; nt < NTI; ++nt) woff[nt] = (unsigned)((((nb * BN + (sub * NTI + nt) * 16 + r) * s.kpad) + 8 * g) * 2);
+    int oy[MT], ox[MT];
+    bool pv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = (mt_i * MT + mt) * 16 + r;
+      pv[mt] = m < M;
+      const int mm = pv[mt] ? m : 0;
+      oy[mt] = mm / s.Wo;
+      ox[mt] = mm - oy[mt] * s.Wo;
+    }
+    f32x4 acc[MT][NTI];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = (f32x4)0.f;
+    // ---- K loop: (ky, kx, source, 32-channel step)
+    int kofs = 0;
+    for (int ky = 0; ky < s.k; ++ky) {
+      for (int kx = 0; kx < s.k; ++kx) {
+        unsigned off[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int iy = oy[mt] * s.stride - pad + ky, ix = ox[mt] * s.stride - pad + kx;
+          const bool inb = pv[mt] && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
+          off[mt] = inb ? (unsigned)(iy * s.W + ix) : EY_OOB;
+        }
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+          if (si >= s.nsrc) break;
+          const int C = s.src_C[si], cs2 = s.src_cs[si] * 2;
+          unsigned po[MT];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) po[mt] = off[mt] == EY_OOB ? EY_OOB : off[mt] * (unsigned)cs2 + 16u * g;
+          for (int c0 = 0; c0 < C; c0 += 32) {
+            const bool chan_ok = c0 + 8 * g < C;  // channel tail of a source that is not a multiple of 32: zeros, not the neighbour's data
+            Vec8<f16> bf[MT], af[NTI];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) BufLoad8<f16>::load(bf[mt], rs[si], chan_ok ? po[mt] : EY_OOB, c0 * 2);
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) BufLoad8<f16>::load(af[nt], rw, woff[nt], (kofs + c0) * 2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt].v, bf[mt].v, acc[mt][nt], 0, 0, 0);
+          }
+          kofs += C;
+        }
+      }
+    }
+    // ---- epilogue (ey_conv2d's): y = res + out_scale * act(acc + bias + bilinear(addz))
+    const int ch0 = nb * BN + g * 4 * NT + 4 * sub * NTI;
+    if (ch0 >= s.Cout) continue;
+    const float* bias = s.bias ? reinterpret_cast<const float*>(s.bias) + wset * s.Cout + ch0 : nullptr;
+    f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img + (long)grp * s.y_g + ch0;
+    const f16* rb = s.has_res ? blk_ptr(ext, s.res, s.res_ext) + (long)b * s.res_img + (long)grp * s.y_g + ch0 : nullptr;
+    const f16* zb = s.has_addz ? blk_ptr(ext, s.addz, s.addz_ext) + (long)b * s.addz_img + (long)grp * s.y_g + ch0 : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      if (!pv[mt]) continue;
+      const int m = (mt_i * MT + mt) * 16 + r;
+      // bilinear source taps of this pixel (F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen
+      // area_pixel_compute_source_index, scale = in/out)
+      long z00 = 0, z01 = 0, z10 = 0, z11 = 0;
+      float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
+      if (zb) {
+        const int Hz = s.addz_H, Wz = s.addz_W;
+        const float sy = fmaxf(s.zsy * (oy[mt] + 0.5f) - 0.5f, 0.f), sx = fmaxf(s.zsx * (ox[mt] + 0.5f) - 0.5f, 0.f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
+        ly1 = sy - y0; lx1 = sx - x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
+        z00 = (long)(y0 * Wz + x0) * s.addz_cs; z01 = (long)(y0 * Wz + x1) * s.addz_cs;
+        z10 = (long)(y1 * Wz + x0) * s.addz_cs; z11 = (long)(y1 * Wz + x1) * s.addz_cs;
+      }
+      f16* yp = yb + (long)m * s.y_cs;
+      const f16* rp = rb ? rb + (long)m * s.res_cs : nullptr;
+#pragma unroll
+      for (int q = 0; q < NTI; ++q) {  // one 4-channel quad at a time (keeps the live register set small)
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[mt][q][j];
+        if (bias) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += bv[j];
+        }
+        if (zb) {
+          float a00[4], a01[4], a10[4], a11[4];
+          load4(zb + z00 + 4 * q, a00); load4(zb + z01 + 4 * q, a01); load4(zb + z10 + 4 * q, a10); load4(zb + z11 + 4 * q, a11);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ey_act(v[j], s.act) * s.out_scale;
+        if (rp) {
+          float rr[4];
+          load4(rp + 4 * q, rr);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += rr[j];
+        }
+        store4(yp + 4 * q, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- depthwise
+// y[p][c] = act(sum_taps x[p + tap][c] * w[tap][c] + bias[c]), k x k, stride 1, pad k/2; thread item = (pixel, 8 channels).
+// DSConv.dw (conv.py:94-97,102; no bias, no activation, result rounded to f16 like the reference's intermediate tensor) and DWConv.
+__device__ void blk_dw(const BlkStage& s, const BlkExt& ext, int b) {
+  const int C = s.src_C[0], cv = C >> 3, HW = s.H * s.W, k = s.k, pad = k >> 1;
+  const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(xb, (unsigned)((((long)HW - 1) * s.src_cs[0] + C) * 2));
+  const f16* w = reinterpret_cast<const f16*>(s.w);
+  const float* bias = reinterpret_cast<const float*>(s.bias);
+  f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
+  for (int i = threadIdx.x; i < HW * cv; i += BLK_THREADS) {
+    const int c8 = (i % cv) * 8, p = i / cv;
+    const int py = p / s.W, px = p - py * s.W;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+      const int iy = py - pad + ky;
+      for (int kx = 0; kx < k; ++kx) {
+        const int ix = px - pad + kx;
+        const bool inb = iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
+        Vec8<f16> xv, wv;
+        BufLoad8<f16>::load(xv, rx, inb ? (unsigned)(((iy * s.W + ix) * s.src_cs[0] + c8) * 2) : EY_OOB);
+        wv.load(w + (ky * k + kx) * C + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += xv.get(j) * wv.get(j);
+      }
+    }
+    Vec8<f16> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.set(j, ey_act(acc[j] + (bias ? bias[c8 + j] : 0.f), s.act));
+    o.store(yb + (long)p * s.y_cs + c8);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- Haar DWT
+// _PywtDWT2D.forward (block.py:3619-3642), same arithmetic as dwt_kernel: taps float32(1/sqrt2)^2; y = [LL | LH | HL | HH] channel blocks.
+__device__ void blk_dwt(const BlkStage& s, const BlkExt& ext, int b) {
+  const int C = s.src_C[0], cv = C >> 3, Ho = s.Ho, Wo = s.Wo;
+  const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
+  f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
+  const float sq = 0.70710678118654752440f, tp = sq * sq;
+  for (int i = threadIdx.x; i < Ho * Wo * cv; i += BLK_THREADS) {
+    const int c8 = (i % cv) * 8, m = i / cv;
+    const int oy = m / Wo, ox = m - oy * Wo;
+    const f16* p00 = xb + (long)((2 * oy) * s.W + 2 * ox) * s.src_cs[0] + c8;
+    Vec8<f16> a, bq, c, d, ll, lh, hl, hh;
+    a.load(p00); bq.load(p00 + s.src_cs[0]); c.load(p00 + (long)s.W * s.src_cs[0]); d.load(p00 + (long)(s.W + 1) * s.src_cs[0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float fa = a.get(j) * tp, fb = bq.get(j) * tp, fc = c.get(j) * tp, fd = d.get(j) * tp;
+      ll.set(j, (fa + fb) + (fc + fd));
+      lh.set(j, (fa - fb) + (fc - fd));
+      hl.set(j, (fa + fb) - (fc + fd));
+      hh.set(j, (fa - fb) - (fc - fd));
+    }
+    f16* yp = yb + (long)m * s.y_cs + c8;
+    ll.store(yp); lh.store(yp + C); hl.store(yp + 2 * C); hh.store(yp + 3 * C);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- SPPF pool chain
+// y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) (block.py:219-223; padding acts as -inf): per chunk of channel octets the H x W planes
+// live in LDS (two buffers), separable max (row pass, column pass) three times; y_k = y + k*C channels of the concat buffer.
+__device__ void blk_pool(const BlkStage& s, const BlkExt& ext, int b, char* smem) {
+  const int C = s.src_C[0], cv = C >> 3, H = s.H, W = s.W, HW = H * W;
+  const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
+  f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
+  const int cvc = max(1, min(cv, (BLK_LDS_BYTES / 2) / (HW * 16)));  // channel octets per chunk (host checked that one fits)
+  Vec8<f16>* A = reinterpret_cast<Vec8<f16>*>(smem);
+  Vec8<f16>* Bf = A + cvc * HW;
+  for (int cg0 = 0; cg0 < cv; cg0 += cvc) {
+    const int ng = min(cvc, cv - cg0);
+    __syncthreads();  // the previous chunk's LDS reads are done
+    for (int i = threadIdx.x; i < ng * HW; i += BLK_THREADS) {
+      const int cg = i % ng, p = i / ng;
+      A[cg * HW + p].load(xb + (long)p * s.src_cs[0] + (cg0 + cg) * 8);
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 3; ++pass) {
+      for (int i = threadIdx.x; i < ng * HW; i += BLK_THREADS) {  // rows
+        const int cg = i / HW, p = i - cg * HW, yy = p / W, xx = p - yy * W;
+        const Vec8<f16>* row = A + cg * HW + yy * W;
+        Vec8<f16> mx = row[xx];
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int x2 = xx + dx;
+          if (dx == 0 || x2 < 0 || x2 >= W) continue;
+          const Vec8<f16> o = row[x2];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx.set(j, fmaxf(mx.get(j), o.get(j)));
+        }
+        Bf[i] = mx;
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < ng * HW; i += BLK_THREADS) {  // columns
+        const int cg = i / HW, p = i - cg * HW, yy = p / W, xx = p - yy * W;
+        const Vec8<f16>* pl = Bf + cg * HW;
+        Vec8<f16> mx = pl[p];
+        for (int dy = -2; dy <= 2; ++dy) {
+          const int y2 = yy + dy;
+          if (dy == 0 || y2 < 0 || y2 >= H) continue;
+          const Vec8<f16> o = pl[y2 * W + xx];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mx.set(j, fmaxf(mx.get(j), o.get(j)));
+        }
+        mx.store(yb + (long)p * s.y_cs + (long)pass * C + (cg0 + cg) * 8);  // y = the y1 slot; y2, y3 follow it at C-channel steps
+        A[i] = mx;  // only element i of A is touched by this thread
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- linear attention
+// LinearAttention.forward core (block.py:3360-3373) for head_dim 64: two heads side by side (512 threads each).
+__device__ void blk_linattn(const BlkStage& s, const BlkExt& ext, int b, char* smem) {
+  LinAttnLds* S = reinterpret_cast<LinAttnLds*>(smem);
+  const int N = s.H * s.W, C = s.Cout, half = threadIdx.x >> 9, tid = threadIdx.x & 511;
+  const f16* qkv = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
+  f16* y = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
+  for (int h0 = 0; h0 < s.heads; h0 += 2) {
+    const int h = h0 + half;
+    __syncthreads();  // LDS of the previous pair is free
+    const f16* qb = qkv + h * 64;
+    linattn_mfma_head(S[half], N, qb, qb + C, qb + 2 * C, s.src_cs[0], y + h * 64, s.y_cs, tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- the kernel
+template <int MT>
+__device__ __forceinline__ void blk_conv_nti(const BlkStage& s, const BlkExt& ext, int b) {
+  switch (s.nti) {
+    case 1: blk_conv<MT, 1>(s, ext, b); break;
+    case 2: blk_conv<MT, 2>(s, ext, b); break;
+    case 4: if constexpr (MT <= 2) blk_conv<MT, 4>(s, ext, b); break;
+    case 5: if constexpr (MT == 1) blk_conv<MT, 5>(s, ext, b); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __restrict__ prog, int nstages, BlkExt ext) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x;
+  for (int si = 0; si < nstages; ++si) {
+    const BlkStage& s = prog[si];
+    switch (s.op) {
+      case EY_BLK_CONV:
+        if (s.mt == 1) blk_conv_nti<1>(s, ext, b);
+        else if (s.mt == 2) blk_conv_nti<2>(s, ext, b);
+        else blk_conv_nti<4>(s, ext, b);
+        break;
+      case EY_BLK_DW: blk_dw(s, ext, b); break;
+      case EY_BLK_DWT: blk_dwt(s, ext, b); break;
+      case EY_BLK_POOL: blk_pool(s, ext, b, smem); break;
+      case EY_BLK_LINATTN: blk_linattn(s, ext, b, smem); break;
+      default: break;
+    }
+    __syncthreads();  // this stage's global writes are visible to the whole workgroup (one CU, one L1) before the next stage reads them
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- host side
+static const int kMT[3] = {1, 2, 4};
+
+extern "C" size_t ey_block_program_bytes(int nstages) { return (size_t)(nstages > 0 ? nstages : 0) * sizeof(ey_block_stage); }
+extern "C" size_t ey_block_stage_sizeof(void) { return sizeof(ey_block_stage); }
+
+static int blk_view_ok(int64_t addr, int ext, int cs, int C, const char* what, int si) {
+  if (ext >= BLK_MAX_EXT) return ey_set_error(EY_EINVAL, "block stage %d: %s: ext index %d out of range", si, what, ext);
+  if (ext < 0 && addr == 0) return ey_set_error(EY_EINVAL, "block stage %d: %s: null pointer", si, what);
+  if (addr % 16) return ey_set_error(EY_EINVAL, "block stage %d: %s: not 16-byte aligned", si, what);
+  if (cs < C || (cs * 2) % 16 || C % 8) return ey_set_error(EY_EINVAL, "block stage %d: %s: cstride %d / channels %d (multiples of 8, 16-byte pixel stride)", si, what, cs, C);
+  return EY_OK;
+}
+
+// Validates the stages, fills the derived fields (packing geometry, wave-tile shape) and writes the device image of the program
+// into out_host (upload it; ey_block_run takes the device copy).
+extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out_host, size_t out_bytes) {
+  EY_CHECK(st && out_host && nstages > 0, "block_compile: null / empty program");
+  EY_CHECK(out_bytes >= ey_block_program_bytes(nstages), "block_compile: output buffer too small");
+  ey_block_stage* o = (ey_block_stage*)out_host;
+  for (int i = 0; i < nstages; ++i) {
+    ey_block_stage s = st[i];
+    EY_CHECK(s.H > 0 && s.W > 0 && s.Ho > 0 && s.Wo > 0 && (long)s.H * s.W <= 4096, "block stage %d: extent %dx%d -> %dx%d (maps up to 4096 pixels)", i, s.H, s.W, s.Ho, s.Wo);
+    int rc;
+    if ((rc = blk_view_ok(s.src[0], s.src_ext[0], s.src_cs[0], s.src_C[0], "src0", i))) return rc;
+    EY_CHECK(s.src_img[0] >= 0 && s.y_img >= 0, "block stage %d: negative image stride", i);
+    switch (s.op) {
+      case EY_BLK_CONV: {
+        EY_CHECK((s.k == 1 || s.k == 3) && (s.stride == 1 || s.stride == 2), "block stage %d: conv k=%d stride=%d", i, s.k, s.stride);
+        EY_CHECK(s.Ho == (s.H + 2 * (s.k / 2) - s.k) / s.stride + 1 && s.Wo == (s.W + 2 * (s.k / 2) - s.k) / s.stride + 1, "block stage %d: conv output extent", i);
+        EY_CHECK(s.nsrc == 1 || s.nsrc == 2, "block stage %d: nsrc=%d", i, s.nsrc);
+        if (s.nsrc == 2 && (rc = blk_view_ok(s.src[1], s.src_ext[1], s.src_cs[1], s.src_C[1], "src1", i))) return rc;
+        EY_CHECK(s.w && s.Cout > 0 && s.Cout % 8 == 0, "block stage %d: conv Cout=%d (multiple of 8) / weights", i, s.Cout);
+        if ((rc = blk_view_ok(s.y, s.y_ext, s.y_cs, s.Cout, "y", i))) return rc;
+        if (s.has_res && (rc = blk_view_ok(s.res, s.res_ext, s.res_cs, s.Cout, "res", i))) return rc;
+        if (s.has_addz && (rc = blk_view_ok(s.addz, s.addz_ext, s.addz_cs, s.Cout, "addz", i))) return rc;
+        EY_CHECK(!s.has_addz || (s.addz_H > 0 && s.addz_W > 0), "block stage %d: addz extent", i);
+        EY_CHECK(!s.bias || ey_aligned(s.bias, 16), "block stage %d: bias alignment", i);
+        if (s.ngroup < 1) s.ngroup = 1;
+        EY_CHECK(s.ngroup == 1 || s.nsrc == 1, "block stage %d: groups need a single source", i);
+        EY_CHECK((s.src_g * 2) % 16 == 0 && (s.y_g * 2) % 16 == 0, "block stage %d: group strides", i);
+        int Cin = 0;
+        for (int j = 0; j < s.nsrc; ++j) Cin += s.src_C[j];
+        s.kpad = ey_conv_kpad(s.k * s.k * Cin);
+        s.nt_pack = ey_conv_pack_nt(s.Cout);
+        s.zsy = s.has_addz ? (float)s.addz_H / (float)s.Ho : 0.f;
+        s.zsx = s.has_addz ? (float)s.addz_W / (float)s.Wo : 0.f;
+        if (s.w_gmax < 0) s.w_gmax = 0;
+        // wave tile (MT pixel tiles x NTI row blocks) with the fewest MFMA rounds over the 16 waves; ties -> the larger tile (less operand traffic)
+        const int M = s.Ho * s.Wo, NT = s.nt_pack, nblk = (s.Cout + 16 * NT - 1) / (16 * NT);
+        long best = -1;
+        for (int a = 0; a < 3; ++a) {
+          for (int nti = 1; nti <= 5; ++nti) {
+            const int mt = kMT[a];
+            if (NT % nti || nti == 3 || mt * nti > 8 || (nti == 5 && mt > 1)) continue;  // (the instantiated wave tiles: <= 8 accumulator blocks, 128 VGPRs)
+            const long items = (long)s.ngroup * ((M + 16 * mt - 1) / (16 * mt)) * nblk * (NT / nti);
+            const long rounds = (items + BLK_WAVES - 1) / BLK_WAVES;
+            const long cost = rounds * mt * nti * 64 - mt * nti;
+            if (best < 0 || cost < best) { best = cost; s.mt = mt; s.nti = nti; }
+          }
+        }
+        break;
+      }
+      case EY_BLK_DW:
+        EY_CHECK((s.k == 3 || s.k == 5 || s.k == 7) && s.w && s.Ho == s.H && s.Wo == s.W, "block stage %d: depthwise k=%d", i, s.k);
+        if ((rc = blk_view_ok(s.y, s.y_ext, s.y_cs, s.src_C[0], "y", i))) return rc;
+        EY_CHECK(ey_aligned(s.w, 16), "block stage %d: depthwise weights alignment", i);
+        break;
+      case EY_BLK_DWT:
+        EY_CHECK(s.H >= 2 && s.W >= 2 && s.Ho == s.H / 2 && s.Wo == s.W / 2, "block stage %d: dwt extent", i);
+        if ((rc = blk_view_ok(s.y, s.y_ext, s.y_cs, 4 * s.src_C[0], "y", i))) return rc;
+        break;
+      case EY_BLK_POOL:
+        EY_CHECK(s.Ho == s.H && s.Wo == s.W && (long)s.H * s.W * 16 * 2 <= BLK_LDS_BYTES, "block stage %d: pool map %dx%d does not fit LDS", i, s.H, s.W);
+        if ((rc = blk_view_ok(s.y, s.y_ext, s.y_cs, 3 * s.src_C[0], "y", i))) return rc;
+        break;
+      case EY_BLK_LINATTN:
+        EY_CHECK(s.heads > 0 && s.heads % 2 == 0 && s.Cout == 64 * s.heads && s.src_C[0] == 3 * s.Cout, "block stage %d: linear attention needs an even number of 64-channel heads", i);
+        EY_CHECK(2 * sizeof(LinAttnLds) <= BLK_LDS_BYTES, "block stage %d: LDS", i);
+        if ((rc = blk_view_ok(s.y, s.y_ext, s.y_cs, s.Cout, "y", i))) return rc;
+        break;
+      default:
+        return ey_set_error(EY_EINVAL, "block stage %d: unknown op %d", i, s.op);
+    }
+    o[i] = s;
+  }
+  return EY_OK;
+}
+
+extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
+  EY_CHECK(program_dev && nstages > 0 && B > 0, "block_run: null / empty program");
+  EY_CHECK(next >= 0 && next <= BLK_MAX_EXT && (next == 0 || ext_ptrs_host), "block_run: %d external tensors (0..%d)", next, BLK_MAX_EXT);
+  BlkExt ext;
+  for (int i = 0; i < BLK_MAX_EXT; ++i) {
+    ext.p[i] = i < next ? (char*)const_cast<void*>(ext_ptrs_host[i]) : nullptr;
+    EY_CHECK(i >= next || (ext.p[i] && ey_aligned(ext.p[i], 16)), "block_run: external tensor %d null / not 16-byte aligned", i);
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BLK_LDS_BYTES) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "block_run: cannot reserve %d B of LDS", BLK_LDS_BYTES);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(block_kernel, dim3(B), dim3(BLK_THREADS), BLK_LDS_BYTES, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext);
+  EY_LAUNCH_CHECK("ey_block_run");
+  return EY_OK;
+}

@@ -7,6 +7,13 @@ import torch
 from .. import _lib as L
 
 TRACE = None  # set by edge-yolo_amd/profiling.py: per-launch HIP-event timing + algorithmic bytes/FLOPs
+RECORD = None  # set by nn/_block.py while a block program is being recorded: wrappers append a stage instead of launching
+
+
+def _no_block(what):
+    if RECORD is not None:
+        from ._block import BlockUnsupported
+        raise BlockUnsupported(what)
 
 
 class _NoTrace:
@@ -106,6 +113,7 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
             raise ValueError(f"conv2d: sources disagree: {[tuple(t.shape) for t in srcs]} up={up}")
     cin = sum(t.shape[1] for t in srcs)
     if len(srcs) > 2 or not igemm_ok(srcs, k, s, p):
+        _no_block("conv shape outside the MFMA kernel")
         if len(srcs) != 1 or up[0] or addz is not None or ngroup != 1 or out_scale != 1.0:
             raise NotImplementedError("this conv shape needs the generic direct kernel, which takes a single plain source")
         return conv2d_direct(mod, srcs[0], folded_fn, k, s, p, 1, act, out=out, res=res, tag=tag)
@@ -155,6 +163,9 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         d.addz, d.addz_cstride, d.addz_H, d.addz_W = addz.data_ptr(), L.cstride(addz), addz.shape[2], addz.shape[3]
     d.ngroup, d.src_gstride, d.y_gstride = ngroup, src_gstride, y_gstride
     d.w_gstride, d.w_gmax = (wset_elems, w_sets - 1) if w_sets > 1 else (0, 0)
+    if RECORD is not None:
+        RECORD.conv(d, srcs, up, out, res, addz, wp, bias, 2.0 * ngroup * B * Ho * Wo * cout * cin * k * k, w_sets * cout * cin * k * k * x0.element_size())
+        return out
     if TRACE is not None:
         M = B * Ho * Wo
         es = x0.element_size()
@@ -186,6 +197,8 @@ def conv_pw_chain(mod, x, fold1, act1, fold2, act2, out):
     """y = act2(W2 . act1(W1 . x + b1) + b2) in ONE kernel (two chained 1x1 convs, registers only).  Returns None when the shape is
     outside the fused kernel (the caller then runs the two convs)."""
     L.require_device(x, "conv_pw_chain")
+    if RECORD is not None:
+        return None  # (block programs run the two convs as two stages)
     x = L.as_nhwc(x)
     B, cin, H, W = x.shape
     if x.dtype != torch.float16 or cin % 8 or (L.cstride(x) * 2) % 16 or x.data_ptr() % 16:
@@ -224,6 +237,7 @@ def conv_pw_chain(mod, x, fold1, act1, fold2, act2, out):
 
 def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""):
     L.require_device(x, "conv2d_direct")
+    _no_block("direct conv")
     if res is not None:
         raise NotImplementedError("residual add is only fused into the MFMA conv")
     x = L.as_nhwc(x)
@@ -254,6 +268,7 @@ def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""
 def stem_conv(mod, x, folded_fn, act, out_dtype, out=None):
     """3x3/s2 conv straight from the NCHW-contiguous image (layer 0)."""
     L.require_device(x, "stem_conv")
+    _no_block("stem conv")
     B, cin, H, W = x.shape
 
     def build():
@@ -287,6 +302,9 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     wk, bias = mod._packed(_dev_key(x, "dw" + tag), build)
     if out is None:
         out = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
+    if RECORD is not None:
+        RECORD.dw(x, wk, bias, k, act, out)
+        return out
     with _tr(f"dwconv_kernel<{k}>", _nb(x, out), 2.0 * x.numel() * k * k, note=f"C{c} {H}x{W}"):
         L.check(L.lib().ey_dwconv(L.dtype_code(x.dtype), B, H, W, c, k, act, x.data_ptr(), L.cstride(x), wk.data_ptr(),
                                   bias.data_ptr() if bias is not None else None, out.data_ptr(), L.cstride(out), L.stream()), "ey_dwconv")
@@ -325,6 +343,16 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
         raise ValueError("dsconv: out= must be an NHWC view of the output shape")
     if res is not None:
         res = L.as_nhwc(res)
+    if RECORD is not None:  # two stages: depthwise (rounded to the storage type like the reference's intermediate tensor) -> pointwise 1x1
+        t = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
+        RECORD.dw(x, wk, dwb, k, dw_act, t)
+        d = L.ConvDesc()
+        d.dtype, d.B, d.H, d.W, d.Ho, d.Wo, d.Cout = L.dtype_code(x.dtype), B, H, W, H, W, cout
+        d.k, d.stride, d.pad, d.act, d.nsrc = 1, 1, 0, act, 1
+        d.src_C[0] = c
+        d.y_cstride, d.out_scale, d.ngroup = L.cstride(out), 1.0, 1
+        RECORD.conv(d, [t], [0], out, res, None, wp, bias, 2.0 * B * H * W * c * cout, cout * c * es)
+        return out
     try:
       rec = _tr(f"dsconv_kernel<{k}>", _nb(x, out, res), 2.0 * B * H * W * c * (k * k + cout), note=f"C{c}->{cout} {H}x{W}{' +res' if res is not None else ''}")
       with rec:
@@ -348,6 +376,11 @@ def dwt_haar(x, out=None):
     B, c, H, W = x.shape
     if out is None:
         out = L.empty_nhwc(B, 4 * c, H // 2, W // 2, x.dtype, x.device)
+    if RECORD is not None:
+        if c % 8 or (L.cstride(x) * x.element_size()) % 16 or x.data_ptr() % 16:
+            _no_block("dwt alignment")
+        RECORD.dwt(x, out)
+        return out
     with _tr("dwt_kernel", _nb(x, out), 4.0 * x.numel()):
         L.check(L.lib().ey_dwt_haar(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), out.data_ptr(), L.cstride(out), L.stream()), "ey_dwt_haar")
     return out
@@ -359,6 +392,9 @@ def sppf_pool(x, y1, y2, y3):
     cs = L.cstride(y1)
     if L.cstride(y2) != cs or L.cstride(y3) != cs:
         raise ValueError("sppf_pool: outputs must share one pixel stride")
+    if RECORD is not None:
+        RECORD.pool(x, y1, y2, y3)
+        return
     with _tr("sppf_kernel", _nb(x, y1, y2, y3)):
         L.check(L.lib().ey_sppf_pool(L.dtype_code(x.dtype), B, H, W, c, x.data_ptr(), L.cstride(x), y1.data_ptr(), y2.data_ptr(), y3.data_ptr(), cs,
                                      L.stream()), "ey_sppf_pool")
@@ -367,6 +403,7 @@ def sppf_pool(x, y1, y2, y3):
 def copy_slice(src, dst, up=0):
     """dst[b,c,y,x] = src[b,c,y>>up,x>>up] (both NHWC views)."""
     B, c, H, W = dst.shape
+    _no_block("copy / concat / upsample")
     with _tr("copy_kernel", _nb(src, dst)):
         L.check(L.lib().ey_copy_nhwc(L.dtype_code(dst.dtype), B, H, W, c, up, src.data_ptr(), L.cstride(src), dst.data_ptr(), L.cstride(dst), L.stream()),
                 "ey_copy_nhwc")
@@ -411,6 +448,9 @@ def linear_attention(qkv, heads, out=None):
     c = c3 // 3
     if out is None:
         out = L.empty_nhwc(B, c, H, W, qkv.dtype, qkv.device)
+    if RECORD is not None:
+        RECORD.linattn(qkv, heads, out)
+        return out
     with _tr("linattn_kernel", _nb(qkv, out), 4.0 * B * H * W * c * (c // heads)):
         L.check(L.lib().ey_linear_attention(L.dtype_code(qkv.dtype), B, H * W, c, heads, qkv.data_ptr(), L.cstride(qkv), out.data_ptr(), L.cstride(out),
                                             L.stream()), "ey_linear_attention")
@@ -419,6 +459,7 @@ def linear_attention(qkv, heads, out=None):
 
 def softmax_attention(qkv, heads, kd, hd, scale, out=None):
     L.require_device(qkv, "softmax_attention")
+    _no_block("softmax attention")
     qkv = L.as_nhwc(qkv)
     B, _, H, W = qkv.shape
     if out is None:
@@ -432,6 +473,7 @@ def softmax_attention(qkv, heads, kd, hd, scale, out=None):
 def head_decode(box, cls, stride, q, pred, a_off):
     """One pyramid level of the fused DGQP + DFL + decode; q = (w1[hid,20], b1, w2[hid], b2) fp32 device tensors or None."""
     L.require_device(box, "head_decode")
+    _no_block("head decode")
     B, _, H, W = box.shape
     nc = cls.shape[1]
     qa = [t.data_ptr() for t in q] if q is not None else [None] * 4

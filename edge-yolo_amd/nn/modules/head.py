@@ -48,6 +48,10 @@ class Detect(nn.Module):
     head_streams = True
     tower_streams = None
     chain = True
+    #  block_fusion: both towers of a pyramid level whose map has at most block_max_pixels pixels (20x20 at 640x640) run as ONE block
+    #                program (nn/_block.py: one persistent workgroup per image) instead of 7 launches; f16 mode only
+    block_fusion = True
+    block_max_pixels = 1024
 
     def __init__(self, nc=80, ch=()):
         super().__init__()
@@ -72,6 +76,7 @@ class Detect(nn.Module):
         self.register_load_state_dict_post_hook(lambda m, _keys: m._reset_caches())
 
     def _reset_caches(self):
+        self.__dict__["_blk"] = {}
         self._tails = {}
         self._stride_f = None
         if hasattr(self, "_qcache"):
@@ -118,6 +123,21 @@ class Detect(nn.Module):
     def _towers(self, i, x, raw):
         self._box_tower(i, x, raw)
         self._cls_tower(i, x, raw)
+
+    def _towers_block(self, i, x, raw):
+        """Both towers of level i as one block program; False when the level is not block-executable (per-layer kernels then)."""
+        if not self.block_fusion or x.dtype != torch.float16 or x.shape[2] * x.shape[3] > self.block_max_pixels or x.shape[0] < 2:
+            return False
+        from .._block import BlockCache
+        cache = self.__dict__.setdefault("_blk", {}).get(i)
+        if cache is None:
+            cache = self._blk[i] = BlockCache(f"head level {i}")
+
+        def chain(t):
+            self._towers(i, t, raw)
+            return [raw]
+
+        return cache.run(chain, [x], [raw]) is not None
 
     @staticmethod
     def _dw_pw(blk, t):
@@ -176,6 +196,18 @@ class Detect(nn.Module):
         for i, t in enumerate(xs):
             H, W = t.shape[2:]
             raw = raws[i]
+            if smap[task] == smap[task + 1]:  # both towers on one stream: small levels go through one block program
+                if fork and smap[task] > 0:
+                    with torch.cuda.stream(self._side[smap[task] - 1]):
+                        done = self._towers_block(i, t, raw)
+                else:
+                    done = self._towers_block(i, t, raw)
+                if done:
+                    task += 2
+                    levels.append((raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), a_off))
+                    a_off += H * W
+                    x[i] = raw
+                    continue
             for tower in (self._box_tower, self._cls_tower):
                 if fork and smap[task] > 0:
                     with torch.cuda.stream(self._side[smap[task] - 1]):

@@ -162,12 +162,89 @@ class BaseModel(nn.Module):
         head in the range (fused NMS candidate build, see Detect.forward)."""
         x, y = state
         y = list(y)
-        for m in self.model[lo:hi]:
+        i = lo
+        while i < hi:
+            j = self._block_end(i, hi, x)
+            if j > i + 1 or (j == i + 1 and i in getattr(self, "_block_of", {}) and self._block_single_ok(i)):
+                got = self._run_block(i, j, x, y)
+                if got is not None:
+                    x, y = got
+                    i = j
+                    continue
+            m = self.model[i]
             if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                x = y[m.f] if isinstance(m.f, int) else [x if j2 == -1 else y[j2] for j2 in m.f]
             x = m(x, nms=head_nms) if (head_nms is not None and isinstance(m, Detect)) else m(x)
             y.append(x if m.i in self.save else None)
+            i += 1
         return x, y
+
+    # ---- block programs (nn/_block.py): runs of consecutive small-map layers as ONE launch -------------------------------------
+    block_fusion = True      # False: always the per-layer kernels
+    block_max_pixels = 1024  # a run is block-executed while its first layer's output map has at most this many pixels (20x20 at 640x640)
+
+    def _block_end(self, i, hi, x):
+        """End (exclusive) of the block-executable run of layers starting at i within [i, hi): the maximal stretch of the precomputed
+        run (`_block_of`: consecutive layers at the coarsest stride) -- or i when layer i starts none / fusion is off / fp32 mode."""
+        runs = getattr(self, "_block_of", None)
+        if not self.block_fusion or not runs or i not in runs or not torch.is_tensor(x) or x.dtype != torch.float16 or not x.is_cuda:
+            return i
+        lo, hi_run, down = runs[i]
+        B, _, H, W = x.shape
+        ratio = down / self._down[i - 1] if i > 0 else down
+        if (H // ratio) * (W // ratio) > self.block_max_pixels or B < 2:
+            return i
+        return min(hi, hi_run)
+
+    def _block_single_ok(self, i):
+        return not isinstance(self.model[i], (Concat, Upsample))
+
+    def _run_block(self, lo, hi, x, y):
+        """Layers [lo, hi) through one block program.  Inputs = the current x and the saved outputs of earlier layers the run reads;
+        outputs = the final x and the saved outputs of the run.  Returns (x, y) or None (not block-executable: per-layer kernels)."""
+        from ._block import BlockCache
+        need = set()
+        for m in self.model[lo:hi]:
+            for f in ([m.f] if isinstance(m.f, int) else m.f):
+                if f != -1:  # (-1 = the previous layer: inside the run, or x for its first layer)
+                    j = f if f >= 0 else m.i + f
+                    if j < lo:
+                        need.add(j)
+        need = sorted(need)
+        if any(y[j] is None for j in need):
+            return None
+        ins = [x] + [y[j] for j in need]
+        if not all(torch.is_tensor(t) for t in ins):
+            return None
+        keep = [m.i for m in self.model[lo:hi] if m.i in self.save]
+
+        def chain(x0, *extra):
+            yy = list(y)
+            for j, t in zip(need, extra):
+                yy[j] = t
+            xx = x0
+            for m in self.model[lo:hi]:
+                if m.f != -1:
+                    xx = yy[m.f] if isinstance(m.f, int) else [xx if j2 == -1 else yy[j2] for j2 in m.f]
+                xx = m(xx)
+                yy.append(xx if m.i in self.save else None)
+            if not torch.is_tensor(xx):
+                from ._block import BlockUnsupported
+                raise BlockUnsupported("the run does not end in a tensor")
+            return [xx] + [yy[i] for i in keep if i != hi - 1]
+
+        caches = self.__dict__.setdefault("_block_caches", {})
+        cache = caches.get((lo, hi))
+        if cache is None:
+            cache = caches[(lo, hi)] = BlockCache(f"layers {lo}-{hi - 1}")
+        outs = cache.run(chain, ins)
+        if outs is None:
+            return None
+        y = list(y)
+        extra = iter(outs[1:])
+        for m in self.model[lo:hi]:
+            y.append(outs[0] if (m.i == hi - 1 and m.i in self.save) else (next(extra) if m.i in self.save else None))
+        return outs[0], y
 
     def fuse(self, verbose=False):
         """Fold every Conv/DWConv BatchNorm into its conv parameters (reference tasks.py:214-242).  DSConv keeps its
@@ -188,6 +265,7 @@ class BaseModel(nn.Module):
         return sum(isinstance(v, bn) for v in self.modules()) < thresh
 
     def _apply(self, fn, *args, **kwargs):
+        self.__dict__["_block_caches"] = {}  # recorded block programs hold packed weights: parameters moved / converted -> re-record
         self = super()._apply(fn, *args, **kwargs)
         m = self.model[-1]
         if isinstance(m, Detect):
@@ -226,6 +304,8 @@ class DetectionModel(BaseModel):
             m.stride = torch.tensor(self._graph_strides(ch))
             self.stride = m.stride
         self._fold_upsample_concat()
+        self._plan_blocks()
+        self.register_load_state_dict_post_hook(lambda m, _keys: m.__dict__.__setitem__("_block_caches", {}))
         for mod in self.modules():  # initialize_weights (utils/torch_utils.py:410-420)
             if isinstance(mod, nn.BatchNorm2d):
                 mod.eps = 1e-3
@@ -253,6 +333,34 @@ class DetectionModel(BaseModel):
             if isinstance(m, Upsample) and m.i not in self.save:
                 cs = consumers.get(m.i, [])
                 m.lazy = bool(cs) and all(isinstance(c, Concat) and c.lazy for c in cs)
+
+    def _plan_blocks(self):
+        """Runs of >= 2 consecutive non-head layers at the coarsest stride (layers 7-10 and 20-22 of the 24-layer YAMLs): candidates for
+        block programs.  `_down[i]` = downsampling factor of layer i's output; `_block_of[i]` = (lo, hi, down) of the run i lies in."""
+        down = []
+        for m in self.model:
+            f = m.f if isinstance(m.f, int) else m.f[0]
+            src = 1.0 if m.i == 0 else (down[f] if f != -1 else down[-1])
+            if isinstance(m, Conv):
+                src *= m.conv.stride[0]
+            elif isinstance(m, Upsample):
+                src /= 2
+            down.append(src)
+        self._down = down
+        top = max(down[:-1]) if len(down) > 1 else 0
+        self._block_of = {}
+        i, n = 0, len(self.model) - 1  # (the head is handled inside Detect)
+        while i < n:
+            if down[i] == top and not isinstance(self.model[i], Upsample):
+                j = i
+                while j < n and down[j] == top and not isinstance(self.model[j], Upsample):
+                    j += 1
+                if j - i >= 2:
+                    for q in range(i, j):
+                        self._block_of[q] = (i, j, top)
+                i = j
+            else:
+                i += 1
 
     def _graph_strides(self, ch):
         down = []

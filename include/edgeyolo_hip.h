@@ -232,6 +232,43 @@ int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const
 int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
                       int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream);
 
+/* ---- Block programs: a chain of layers on SMALL feature maps (<= 4096 pixels per image; built for the 20x20 part of the network at
+ * 640x640: stride-2 Conv -> DSC3K2_Wavelet -> SPPF -> C2PSA_LinearAttention, nn/modules/block.py:204-223,3412-3497,3749-3788; the
+ * last neck block; the 20x20 Detect towers, head.py:59-70) executed by ONE launch: one persistent 1024-thread workgroup per image
+ * walks the stages below with a workgroup barrier between them.  Each stage is one of the operators above with the same
+ * arithmetic (f16 storage between stages, fp32 accumulate); f16 only.
+ *
+ * A tensor reference is (addr, ext): ext < 0 -> addr is an absolute device pointer (weights, intermediates owned by the caller for
+ * the life of the program); ext >= 0 -> addr is a BYTE offset into the ext-th external tensor handed to ey_block_run (the chain's
+ * inputs and outputs, which change from call to call).  *_img = elements between consecutive images of that tensor; *_cs = pixel
+ * stride (elements) as everywhere in this ABI. */
+enum { EY_BLK_CONV = 0, EY_BLK_DW = 1, EY_BLK_DWT = 2, EY_BLK_POOL = 3, EY_BLK_LINATTN = 4 };
+typedef struct {
+  int32_t op;
+  int32_t H, W, Ho, Wo;        /* input / output extent of the stage */
+  int32_t k, stride, act;      /* CONV: k in {1,3}, stride in {1,2}, pad k/2.  DW: k in {3,5,7}, stride 1 */
+  int32_t nsrc;                /* CONV: 1 or 2 virtually concatenated sources; others: 1 */
+  int64_t src[2]; int32_t src_ext[2]; int64_t src_img[2]; int32_t src_cs[2]; int32_t src_C[2];
+  const void* w;               /* CONV: ey_conv_pack_weight layout (group sets w_g elements apart); DW: [k][k][C] f16 */
+  const float* bias;           /* CONV: [sets][Cout] fp32 or NULL; DW: [C] fp32 or NULL */
+  int64_t w_g; int32_t w_gmax;
+  int64_t y; int32_t y_ext; int64_t y_img; int32_t y_cs; int32_t Cout;   /* POOL: y = the y1 slot (y2, y3 follow at C-channel steps); LINATTN: Cout = C */
+  int32_t has_res; int64_t res; int32_t res_ext; int64_t res_img; int32_t res_cs;
+  int32_t has_addz; int64_t addz; int32_t addz_ext; int64_t addz_img; int32_t addz_cs, addz_H, addz_W;
+  float out_scale;
+  int32_t ngroup; int64_t src_g, y_g;   /* CONV: channel-offset groups as in ey_conv_desc */
+  int32_t heads;               /* LINATTN: heads of 64 channels, even */
+  /* filled by ey_block_compile */
+  int32_t kpad, nt_pack, mt, nti;
+  float zsy, zsx;
+} ey_block_stage;
+size_t ey_block_stage_sizeof(void);
+size_t ey_block_program_bytes(int nstages);
+/* host -> host: validate + derive; upload `out_host` (ey_block_program_bytes bytes) to the device afterwards. */
+int ey_block_compile(const ey_block_stage* stages_host, int nstages, void* out_host, size_t out_bytes);
+/* One launch: grid = B workgroups.  ext_ptrs_host: the `next` (<= 8) external tensors' device base pointers (host array, read at call time). */
+int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream);
+
 /* ---- K11: batched per-image NMS (non_max_suppression, utils/ops.py:230-316, and the torchvision.ops.nms it calls
  * at :296).  multi_label=0: best class per anchor (predict, ops.py:273-275); multi_label=1: one candidate per
  * (anchor, class) pair above conf (validation, ops.py:270-272; needs the _ml workspace).
