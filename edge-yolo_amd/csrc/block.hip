@@ -34,40 +34,102 @@ __device__ __forceinline__ const f16* blk_ptr(const BlkExt& e, int64_t addr, int
   return reinterpret_cast<const f16*>(ext >= 0 ? e.p[ext] + addr : reinterpret_cast<char*>(addr));
 }
 
+// ---------------------------------------------------------------------------------------------------------------- conv epilogue
+// ey_conv2d's: y = res + out_scale * act(acc + bias + bilinear(addz)) for one pixel (m = oy*Wo + ox) and the 4*NTI consecutive
+// channels a lane owns; the pointers are already offset to the lane's first channel.  One 4-channel quad at a time (small live set).
+struct BlkEpi {
+  const float* bias;
+  f16* y;
+  const f16* res;
+  const f16* z;
+  int y_cs, res_cs, addz_cs, Hz, Wz, act;
+  float zsy, zsx, out_scale;
+};
+template <int NTI>
+__device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)[NTI], int m, int oy, int ox) {
+  long z00 = 0, z01 = 0, z10 = 0, z11 = 0;
+  float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
+  if (e.z) {  // F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen area_pixel_compute_source_index, scale = in/out
+    const float sy = fmaxf(e.zsy * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(e.zsx * (ox + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, e.Hz - 1), x1 = min(x0 + 1, e.Wz - 1);
+    ly1 = sy - y0; lx1 = sx - x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
+    z00 = (long)(y0 * e.Wz + x0) * e.addz_cs; z01 = (long)(y0 * e.Wz + x1) * e.addz_cs;
+    z10 = (long)(y1 * e.Wz + x0) * e.addz_cs; z11 = (long)(y1 * e.Wz + x1) * e.addz_cs;
+  }
+  f16* yp = e.y + (long)m * e.y_cs;
+  const f16* rp = e.res ? e.res + (long)m * e.res_cs : nullptr;
+#pragma unroll
+  for (int q = 0; q < NTI; ++q) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = acc[q][j];
+    if (e.bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(e.bias + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += bv[j];
+    }
+    if (e.z) {
+      float a00[4], a01[4], a10[4], a11[4];
+      load4(e.z + z00 + 4 * q, a00); load4(e.z + z01 + 4 * q, a01); load4(e.z + z10 + 4 * q, a10); load4(e.z + z11 + 4 * q, a11);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ey_act(v[j], e.act) * e.out_scale;
+    if (rp) {
+      float rr[4];
+      load4(rp + 4 * q, rr);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += rr[j];
+    }
+    store4(yp + 4 * q, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- conv
 // Work item = (group, MT pixel tiles of 16, NTI of the NT 16-channel MFMA row blocks of one packed block tile); the 16 waves walk
 // the items round-robin, consecutive waves share a pixel tile (its fragments hit in L1).  A = packed weights (row permutation of
 // ey_conv_pack_weight: lane (r, g) ends up with 4*NTI CONSECUTIVE channels of pixel r), B = pixels by range-checked buffer loads
 // (padding taps, pixel tails and channel tails read zeros).
 template <int MT, int NTI>
-__device__ void blk_conv(const BlkStage& s, const BlkExt& ext, int b) {
+__device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b) {
+  // the stage descriptor lives in global memory: every field the loops use is read ONCE into (scalar) registers here
+  const int H = sg.H, W = sg.W, Wo = sg.Wo, kk = sg.k, stride = sg.stride, nsrc = sg.nsrc, Cout = sg.Cout, kpad = sg.kpad;
+  const int C0 = sg.src_C[0], C1 = sg.src_C[1], cs0 = sg.src_cs[0], cs1 = sg.src_cs[1];
+  const int ngroup = sg.ngroup, w_gmax = sg.w_gmax, act = sg.act;
+  const long src_g = sg.src_g, y_g = sg.y_g, w_g = sg.w_g;
+  const f16* src0 = blk_ptr(ext, sg.src[0], sg.src_ext[0]) + (long)b * sg.src_img[0];
+  const f16* src1 = nsrc > 1 ? blk_ptr(ext, sg.src[1], sg.src_ext[1]) + (long)b * sg.src_img[1] : src0;
+  const f16* wptr = reinterpret_cast<const f16*>(sg.w);
+  const float* bptr = reinterpret_cast<const float*>(sg.bias);
+  f16* yptr = const_cast<f16*>(blk_ptr(ext, sg.y, sg.y_ext)) + (long)b * sg.y_img;
+  const int y_cs = sg.y_cs, res_cs = sg.res_cs, addz_cs = sg.addz_cs, Hz = sg.addz_H, Wz = sg.addz_W;
+  const f16* resptr = sg.has_res ? blk_ptr(ext, sg.res, sg.res_ext) + (long)b * sg.res_img : nullptr;
+  const f16* zptr = sg.has_addz ? blk_ptr(ext, sg.addz, sg.addz_ext) + (long)b * sg.addz_img : nullptr;
+  const float zsy = sg.zsy, zsx = sg.zsx, out_scale = sg.out_scale;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
-  const int M = s.Ho * s.Wo, NT = s.nt_pack, BN = 16 * NT;
+  const int M = sg.Ho * Wo, NT = sg.nt_pack, BN = 16 * NT;
   const int mtiles = (M + 16 * MT - 1) / (16 * MT);
-  const int nsub = NT / NTI, nblk = (s.Cout + BN - 1) / BN;
-  const int per_tile = nblk * nsub;
-  const int nitems = s.ngroup * mtiles * per_tile;
-  const int pad = s.k >> 1;
+  const int nsub = NT / NTI, nblk = (Cout + BN - 1) / BN;
+  const int nitems = ngroup * mtiles * nblk * nsub;
+  const int pad = kk >> 1;
+  const unsigned bytes0 = (unsigned)((((long)H * W - 1) * cs0 + C0) * 2), bytes1 = (unsigned)((((long)H * W - 1) * cs1 + C1) * 2);
   for (int it = wave; it < nitems; it += BLK_WAVES) {
     const int sub = it % nsub;
     int t = it / nsub;
     const int nb = t % nblk;
     t /= nblk;
     const int mt_i = t % mtiles, grp = t / mtiles;
-    const int wset = min(grp, s.w_gmax);
+    const int wset = min(grp, w_gmax);
     // ---- operands
     __amdgpu_buffer_rsrc_t rs[2];
-#pragma unroll
-    for (int si = 0; si < 2; ++si) {
-      const int sj = si < s.nsrc ? si : 0;
-      const f16* base = blk_ptr(ext, s.src[sj], s.src_ext[sj]) + (long)b * s.src_img[sj] + (si == 0 ? (long)grp * s.src_g : 0L);
-      rs[si] = ey_rsrc(base, (unsigned)((((long)s.H * s.W - 1) * s.src_cs[sj] + s.src_C[sj]) * 2));
-    }
-    const f16* wbase = reinterpret_cast<const f16*>(s.w) + (long)wset * s.w_g;
-    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(wbase, (unsigned)((long)nblk * BN * s.kpad * 2));
+    rs[0] = ey_rsrc(src0 + (long)grp * src_g, bytes0);
+    rs[1] = ey_rsrc(src1, bytes1);
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(wptr + (long)wset * w_g, (unsigned)((long)nblk * BN * kpad * 2));
     unsigned woff[NTI];
 #pragma unroll
-    for (int nt = 0; nt < NTI; ++nt) woff[nt] = (unsigned)((((nb * BN + (sub * NTI + nt) * 16 + r) * s.kpad) + 8 * g) * 2);
+    for (int nt = 0; nt < NTI; ++nt) woff[nt] = (unsigned)((((nb * BN + (sub * NTI + nt) * 16 + r) * kpad) + 8 * g) * 2);
     int oy[MT], ox[MT];
     bool pv[MT];
 #pragma unroll
@@ -75,101 +137,75 @@ __device__ void blk_conv(const BlkStage& s, const BlkExt& ext, int b) {
       const int m = (mt_i * MT + mt) * 16 + r;
       pv[mt] = m < M;
       const int mm = pv[mt] ? m : 0;
-      oy[mt] = mm / s.Wo;
-      ox[mt] = mm - oy[mt] * s.Wo;
+      oy[mt] = mm / Wo;
+      ox[mt] = mm - oy[mt] * Wo;
     }
     f32x4 acc[MT][NTI];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = (f32x4)0.f;
-    // ---- K loop: (ky, kx, source, 32-channel step)
-    int kofs = 0;
-    for (int ky = 0; ky < s.k; ++ky) {
-      for (int kx = 0; kx < s.k; ++kx) {
-        unsigned off[MT];
+    // ---- K loop: k-steps = (ky, kx, source, 32-channel step), walked U at a time: the loads of U steps are issued back to back
+    // (a lone step is one dependent round trip to L2, ~1 us: the loop would be pure latency), then their MFMAs
+    constexpr int U = (MT + NTI <= 3) ? 4 : (MT + NTI <= 5) ? 3 : 2;
+    int ky = 0, kx = 0, si = 0, c0 = 0, kofs = 0;
+    bool more = true;
+    while (more) {
+      Vec8<f16> bf[U][MT], af[U][NTI];
+      bool live[U];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int iy = oy[mt] * s.stride - pad + ky, ix = ox[mt] * s.stride - pad + kx;
-          const bool inb = pv[mt] && iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
-          off[mt] = inb ? (unsigned)(iy * s.W + ix) : EY_OOB;
-        }
+      for (int u = 0; u < U; ++u) {
+        live[u] = more;
+        if (more) {  // (wave-uniform)
+          const int C = si == 0 ? C0 : C1, cs2 = (si == 0 ? cs0 : cs1) * 2;
+          const bool chan_ok = c0 + 8 * g < C;  // channel tail of a source that is not a multiple of 32: zeros, not the neighbour's data
 #pragma unroll
-        for (int si = 0; si < 2; ++si) {
-          if (si >= s.nsrc) break;
-          const int C = s.src_C[si], cs2 = s.src_cs[si] * 2;
-          unsigned po[MT];
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) po[mt] = off[mt] == EY_OOB ? EY_OOB : off[mt] * (unsigned)cs2 + 16u * g;
-          for (int c0 = 0; c0 < C; c0 += 32) {
-            const bool chan_ok = c0 + 8 * g < C;  // channel tail of a source that is not a multiple of 32: zeros, not the neighbour's data
-            Vec8<f16> bf[MT], af[NTI];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) BufLoad8<f16>::load(bf[mt], rs[si], chan_ok ? po[mt] : EY_OOB, c0 * 2);
-#pragma unroll
-            for (int nt = 0; nt < NTI; ++nt) BufLoad8<f16>::load(af[nt], rw, woff[nt], (kofs + c0) * 2);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt].v, bf[mt].v, acc[mt][nt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) {
+            const int iy = oy[mt] * stride - pad + ky, ix = ox[mt] * stride - pad + kx;
+            const bool inb = chan_ok && pv[mt] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const unsigned po = inb ? (unsigned)(iy * W + ix) * (unsigned)cs2 + 16u * g : EY_OOB;
+            if (si == 0) BufLoad8<f16>::load(bf[u][mt], rs[0], po, c0 * 2);
+            else BufLoad8<f16>::load(bf[u][mt], rs[1], po, c0 * 2);
           }
-          kofs += C;
+#pragma unroll
+          for (int nt = 0; nt < NTI; ++nt) BufLoad8<f16>::load(af[u][nt], rw, woff[nt], (kofs + c0) * 2);
+          // advance the (wave-uniform) k-step iterator
+          c0 += 32;
+          if (c0 >= C) {
+            kofs += C;
+            c0 = 0;
+            if (++si >= nsrc) {
+              si = 0;
+              if (++kx >= kk) {
+                kx = 0;
+                if (++ky >= kk) more = false;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (live[u]) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][nt].v, bf[u][mt].v, acc[mt][nt], 0, 0, 0);
         }
       }
     }
-    // ---- epilogue (ey_conv2d's): y = res + out_scale * act(acc + bias + bilinear(addz))
+    // ---- epilogue
     const int ch0 = nb * BN + g * 4 * NT + 4 * sub * NTI;
-    if (ch0 >= s.Cout) continue;
-    const float* bias = s.bias ? reinterpret_cast<const float*>(s.bias) + wset * s.Cout + ch0 : nullptr;
-    f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img + (long)grp * s.y_g + ch0;
-    const f16* rb = s.has_res ? blk_ptr(ext, s.res, s.res_ext) + (long)b * s.res_img + (long)grp * s.y_g + ch0 : nullptr;
-    const f16* zb = s.has_addz ? blk_ptr(ext, s.addz, s.addz_ext) + (long)b * s.addz_img + (long)grp * s.y_g + ch0 : nullptr;
+    if (ch0 >= Cout) continue;
+    BlkEpi e;
+    e.bias = bptr ? bptr + wset * Cout + ch0 : nullptr;
+    e.y = yptr + (long)grp * y_g + ch0;
+    e.res = resptr ? resptr + (long)grp * y_g + ch0 : nullptr;
+    e.z = zptr ? zptr + (long)grp * y_g + ch0 : nullptr;
+    e.y_cs = y_cs; e.res_cs = res_cs; e.addz_cs = addz_cs; e.Hz = Hz; e.Wz = Wz; e.act = act; e.zsy = zsy; e.zsx = zsx; e.out_scale = out_scale;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      if (!pv[mt]) continue;
-      const int m = (mt_i * MT + mt) * 16 + r;
-      // bilinear source taps of this pixel (F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen
-      // area_pixel_compute_source_index, scale = in/out)
-      long z00 = 0, z01 = 0, z10 = 0, z11 = 0;
-      float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
-      if (zb) {
-        const int Hz = s.addz_H, Wz = s.addz_W;
-        const float sy = fmaxf(s.zsy * (oy[mt] + 0.5f) - 0.5f, 0.f), sx = fmaxf(s.zsx * (ox[mt] + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = min(y0 + 1, Hz - 1), x1 = min(x0 + 1, Wz - 1);
-        ly1 = sy - y0; lx1 = sx - x0; ly0 = 1.f - ly1; lx0 = 1.f - lx1;
-        z00 = (long)(y0 * Wz + x0) * s.addz_cs; z01 = (long)(y0 * Wz + x1) * s.addz_cs;
-        z10 = (long)(y1 * Wz + x0) * s.addz_cs; z11 = (long)(y1 * Wz + x1) * s.addz_cs;
-      }
-      f16* yp = yb + (long)m * s.y_cs;
-      const f16* rp = rb ? rb + (long)m * s.res_cs : nullptr;
-#pragma unroll
-      for (int q = 0; q < NTI; ++q) {  // one 4-channel quad at a time (keeps the live register set small)
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[mt][q][j];
-        if (bias) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + 4 * q);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += bv[j];
-        }
-        if (zb) {
-          float a00[4], a01[4], a10[4], a11[4];
-          load4(zb + z00 + 4 * q, a00); load4(zb + z01 + 4 * q, a01); load4(zb + z10 + 4 * q, a10); load4(zb + z11 + 4 * q, a11);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = ey_act(v[j], s.act) * s.out_scale;
-        if (rp) {
-          float rr[4];
-          load4(rp + 4 * q, rr);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += rr[j];
-        }
-        store4(yp + 4 * q, v);
-      }
-    }
+    for (int mt = 0; mt < MT; ++mt)
+      if (pv[mt]) blk_epilogue<NTI>(e, acc[mt], (mt_i * MT + mt) * 16 + r, oy[mt], ox[mt]);
   }
 }
 
@@ -177,15 +213,15 @@ __device__ void blk_conv(const BlkStage& s, const BlkExt& ext, int b) {
 // y[p][c] = act(sum_taps x[p + tap][c] * w[tap][c] + bias[c]), k x k, stride 1, pad k/2; thread item = (pixel, 8 channels).
 // DSConv.dw (conv.py:94-97,102; no bias, no activation, result rounded to f16 like the reference's intermediate tensor) and DWConv.
 __device__ void blk_dw(const BlkStage& s, const BlkExt& ext, int b) {
-  const int C = s.src_C[0], cv = C >> 3, HW = s.H * s.W, k = s.k, pad = k >> 1;
+  const int C = s.src_C[0], cv = C >> 3, H = s.H, W = s.W, HW = H * W, k = s.k, pad = k >> 1, xcs = s.src_cs[0], ycs = s.y_cs, act = s.act;
   const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
-  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(xb, (unsigned)((((long)HW - 1) * s.src_cs[0] + C) * 2));
+  const __amdgpu_buffer_rsrc_t rx = ey_rsrc(xb, (unsigned)((((long)HW - 1) * xcs + C) * 2));
   const f16* w = reinterpret_cast<const f16*>(s.w);
   const float* bias = reinterpret_cast<const float*>(s.bias);
   f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
   for (int i = threadIdx.x; i < HW * cv; i += BLK_THREADS) {
     const int c8 = (i % cv) * 8, p = i / cv;
-    const int py = p / s.W, px = p - py * s.W;
+    const int py = p / W, px = p - py * W;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -193,9 +229,9 @@ __device__ void blk_dw(const BlkStage& s, const BlkExt& ext, int b) {
       const int iy = py - pad + ky;
       for (int kx = 0; kx < k; ++kx) {
         const int ix = px - pad + kx;
-        const bool inb = iy >= 0 && iy < s.H && ix >= 0 && ix < s.W;
+        const bool inb = iy >= 0 && iy < H && ix >= 0 && ix < W;
         Vec8<f16> xv, wv;
-        BufLoad8<f16>::load(xv, rx, inb ? (unsigned)(((iy * s.W + ix) * s.src_cs[0] + c8) * 2) : EY_OOB);
+        BufLoad8<f16>::load(xv, rx, inb ? (unsigned)(((iy * W + ix) * xcs + c8) * 2) : EY_OOB);
         wv.load(w + (ky * k + kx) * C + c8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += xv.get(j) * wv.get(j);
@@ -203,24 +239,24 @@ __device__ void blk_dw(const BlkStage& s, const BlkExt& ext, int b) {
     }
     Vec8<f16> o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.set(j, ey_act(acc[j] + (bias ? bias[c8 + j] : 0.f), s.act));
-    o.store(yb + (long)p * s.y_cs + c8);
+    for (int j = 0; j < 8; ++j) o.set(j, ey_act(acc[j] + (bias ? bias[c8 + j] : 0.f), act));
+    o.store(yb + (long)p * ycs + c8);
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- Haar DWT
 // _PywtDWT2D.forward (block.py:3619-3642), same arithmetic as dwt_kernel: taps float32(1/sqrt2)^2; y = [LL | LH | HL | HH] channel blocks.
 __device__ void blk_dwt(const BlkStage& s, const BlkExt& ext, int b) {
-  const int C = s.src_C[0], cv = C >> 3, Ho = s.Ho, Wo = s.Wo;
+  const int C = s.src_C[0], cv = C >> 3, Ho = s.Ho, Wo = s.Wo, W = s.W, xcs = s.src_cs[0], ycs = s.y_cs;
   const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
   f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
   const float sq = 0.70710678118654752440f, tp = sq * sq;
   for (int i = threadIdx.x; i < Ho * Wo * cv; i += BLK_THREADS) {
     const int c8 = (i % cv) * 8, m = i / cv;
     const int oy = m / Wo, ox = m - oy * Wo;
-    const f16* p00 = xb + (long)((2 * oy) * s.W + 2 * ox) * s.src_cs[0] + c8;
+    const f16* p00 = xb + (long)((2 * oy) * W + 2 * ox) * xcs + c8;
     Vec8<f16> a, bq, c, d, ll, lh, hl, hh;
-    a.load(p00); bq.load(p00 + s.src_cs[0]); c.load(p00 + (long)s.W * s.src_cs[0]); d.load(p00 + (long)(s.W + 1) * s.src_cs[0]);
+    a.load(p00); bq.load(p00 + xcs); c.load(p00 + (long)W * xcs); d.load(p00 + (long)(W + 1) * xcs);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float fa = a.get(j) * tp, fb = bq.get(j) * tp, fc = c.get(j) * tp, fd = d.get(j) * tp;
@@ -229,7 +265,7 @@ __device__ void blk_dwt(const BlkStage& s, const BlkExt& ext, int b) {
       hl.set(j, (fa + fb) - (fc + fd));
       hh.set(j, (fa - fb) - (fc - fd));
     }
-    f16* yp = yb + (long)m * s.y_cs + c8;
+    f16* yp = yb + (long)m * ycs + c8;
     ll.store(yp); lh.store(yp + C); hl.store(yp + 2 * C); hh.store(yp + 3 * C);
   }
 }
@@ -238,7 +274,7 @@ __device__ void blk_dwt(const BlkStage& s, const BlkExt& ext, int b) {
 // y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2) (block.py:219-223; padding acts as -inf): per chunk of channel octets the H x W planes
 // live in LDS (two buffers), separable max (row pass, column pass) three times; y_k = y + k*C channels of the concat buffer.
 __device__ void blk_pool(const BlkStage& s, const BlkExt& ext, int b, char* smem) {
-  const int C = s.src_C[0], cv = C >> 3, H = s.H, W = s.W, HW = H * W;
+  const int C = s.src_C[0], cv = C >> 3, H = s.H, W = s.W, HW = H * W, xcs = s.src_cs[0], ycs = s.y_cs;
   const f16* xb = blk_ptr(ext, s.src[0], s.src_ext[0]) + (long)b * s.src_img[0];
   f16* yb = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
   const int cvc = max(1, min(cv, (BLK_LDS_BYTES / 2) / (HW * 16)));  // channel octets per chunk (host checked that one fits)
@@ -249,7 +285,7 @@ __device__ void blk_pool(const BlkStage& s, const BlkExt& ext, int b, char* smem
     __syncthreads();  // the previous chunk's LDS reads are done
     for (int i = threadIdx.x; i < ng * HW; i += BLK_THREADS) {
       const int cg = i % ng, p = i / ng;
-      A[cg * HW + p].load(xb + (long)p * s.src_cs[0] + (cg0 + cg) * 8);
+      A[cg * HW + p].load(xb + (long)p * xcs + (cg0 + cg) * 8);
     }
     __syncthreads();
     for (int pass = 0; pass < 3; ++pass) {
@@ -278,7 +314,7 @@ __device__ void blk_pool(const BlkStage& s, const BlkExt& ext, int b, char* smem
 #pragma unroll
           for (int j = 0; j < 8; ++j) mx.set(j, fmaxf(mx.get(j), o.get(j)));
         }
-        mx.store(yb + (long)p * s.y_cs + (long)pass * C + (cg0 + cg) * 8);  // y = the y1 slot; y2, y3 follow it at C-channel steps
+        mx.store(yb + (long)p * ycs + (long)pass * C + (cg0 + cg) * 8);  // y = the y1 slot; y2, y3 follow it at C-channel steps
         A[i] = mx;  // only element i of A is touched by this thread
       }
       __syncthreads();
@@ -313,9 +349,10 @@ __device__ __forceinline__ void blk_conv_nti(const BlkStage& s, const BlkExt& ex
   }
 }
 
-__global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __restrict__ prog, int nstages, BlkExt ext) {
+__global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __restrict__ prog, int nstages, BlkExt ext, long long* __restrict__ tstamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int b = blockIdx.x;
+  if (tstamps && b == 0 && threadIdx.x == 0) tstamps[0] = wall_clock64();
   for (int si = 0; si < nstages; ++si) {
     const BlkStage& s = prog[si];
     switch (s.op) {
@@ -331,6 +368,7 @@ __global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __re
       default: break;
     }
     __syncthreads();  // this stage's global writes are visible to the whole workgroup (one CU, one L1) before the next stage reads them
+    if (tstamps && b == 0 && threadIdx.x == 0) tstamps[si + 1] = wall_clock64();  // (developer timing, ey_block_run_timed)
   }
 }
 
@@ -382,7 +420,9 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
         s.zsy = s.has_addz ? (float)s.addz_H / (float)s.Ho : 0.f;
         s.zsx = s.has_addz ? (float)s.addz_W / (float)s.Wo : 0.f;
         if (s.w_gmax < 0) s.w_gmax = 0;
-        // wave tile (MT pixel tiles x NTI row blocks) with the fewest MFMA rounds over the 16 waves; ties -> the larger tile (less operand traffic)
+        s.lds = 0;
+        // wave tile (MT pixel tiles x NTI row blocks): operands come fragment-wise through the CU's 64 B/clk vector-memory path, so a
+        // round of the 16 waves costs ~(MT + NTI) fragment loads per k-step (the MFMAs hide behind them): fewest rounds x loads wins
         const int M = s.Ho * s.Wo, NT = s.nt_pack, nblk = (s.Cout + 16 * NT - 1) / (16 * NT);
         long best = -1;
         for (int a = 0; a < 3; ++a) {
@@ -391,7 +431,7 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
             if (NT % nti || nti == 3 || mt * nti > 8 || (nti == 5 && mt > 1)) continue;  // (the instantiated wave tiles: <= 8 accumulator blocks, 128 VGPRs)
             const long items = (long)s.ngroup * ((M + 16 * mt - 1) / (16 * mt)) * nblk * (NT / nti);
             const long rounds = (items + BLK_WAVES - 1) / BLK_WAVES;
-            const long cost = rounds * mt * nti * 64 - mt * nti;
+            const long cost = rounds * (mt + nti) * 16 + mt * nti;
             if (best < 0 || cost < best) { best = cost; s.mt = mt; s.nti = nti; }
           }
         }
@@ -423,7 +463,7 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
   return EY_OK;
 }
 
-extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
+static int block_launch(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, long long* tstamps, ey_stream_t stream) {
   EY_CHECK(program_dev && nstages > 0 && B > 0, "block_run: null / empty program");
   EY_CHECK(next >= 0 && next <= BLK_MAX_EXT && (next == 0 || ext_ptrs_host), "block_run: %d external tensors (0..%d)", next, BLK_MAX_EXT);
   BlkExt ext;
@@ -437,7 +477,16 @@ extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const v
       return ey_set_error(EY_ELAUNCH, "block_run: cannot reserve %d B of LDS", BLK_LDS_BYTES);
     attr_done = true;
   }
-  hipLaunchKernelGGL(block_kernel, dim3(B), dim3(BLK_THREADS), BLK_LDS_BYTES, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext);
+  hipLaunchKernelGGL(block_kernel, dim3(B), dim3(BLK_THREADS), BLK_LDS_BYTES, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext, tstamps);
   EY_LAUNCH_CHECK("ey_block_run");
   return EY_OK;
+}
+
+extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
+  return block_launch(program_dev, nstages, B, ext_ptrs_host, next, nullptr, stream);
+}
+// developer tool: same launch; workgroup 0 also writes wall_clock64() (100 MHz) at the start and after every stage into tstamps_dev[nstages + 1]
+extern "C" int ey_block_run_timed(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, long long* tstamps_dev, ey_stream_t stream) {
+  EY_CHECK(tstamps_dev, "block_run_timed: null timestamp buffer");
+  return block_launch(program_dev, nstages, B, ext_ptrs_host, next, tstamps_dev, stream);
 }

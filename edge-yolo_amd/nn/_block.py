@@ -26,7 +26,7 @@ class BlockRecorder:
     def __init__(self, dtype):
         if dtype != torch.float16:
             raise BlockUnsupported("block programs are f16 only")
-        self.stages, self.refs, self.keep = [], [], []
+        self.stages, self.refs, self.keep, self.desc = [], [], [], []
         self.flops, self.wbytes = 0.0, 0
 
     # -- helpers
@@ -61,6 +61,10 @@ class BlockRecorder:
 
     def _push(self, st):
         self.stages.append(st)
+        names = {L.BLK_CONV: "conv", L.BLK_DW: "dw", L.BLK_DWT: "dwt", L.BLK_POOL: "pool", L.BLK_LINATTN: "linattn"}
+        cin = st.src_C[0] + (st.src_C[1] if st.nsrc > 1 else 0)
+        self.desc.append(f"{names[st.op]:7s} k{st.k} s{st.stride} {cin:4d}->{st.Cout:4d} {st.H}x{st.W}->{st.Ho}x{st.Wo} g{st.ngroup}"
+                         f"{' +res' if st.has_res else ''}{' +addz' if st.has_addz else ''}")
 
     # -- operators
     def conv(self, d, srcs, up, out, res, addz, wp, bias, flops, wbytes):
@@ -183,7 +187,11 @@ class BlockRecorder:
         except L.HipLibraryError as e:
             raise BlockUnsupported(str(e)) from e
         dev = ins[0].device
-        return BlockProgram(host.to(dev), n, ins, outs, ext, [t for t in self.keep if t is not None], self.flops, self.wbytes, tag)
+        prog = BlockProgram(host.to(dev), n, ins, outs, ext, [t for t in self.keep if t is not None], self.flops, self.wbytes, tag)
+        tiles = torch.frombuffer(bytearray(host.numpy().tobytes()), dtype=torch.uint8)
+        cs = (L.BlockStage * n).from_buffer_copy(tiles.numpy().tobytes())
+        prog.desc = [f"{d}  tile {cs[i].mt}x{cs[i].nti}{' lds' if cs[i].lds else ''}" if cs[i].op == L.BLK_CONV else d for i, d in enumerate(self.desc)]
+        return prog
 
 
 def _sig(t):
@@ -203,6 +211,7 @@ class BlockProgram:
         self.out_ext = [base.index(t.untyped_storage().data_ptr()) for t in outs]
         self.alg_bytes = sum(t.numel() * t.element_size() for t in list(ins) + list(outs)) + wbytes
         self.first_outs = list(outs)  # the tensors allocated while recording serve the first run
+        self.timing = None
 
     def matches(self, ins):
         return len(ins) == len(self.in_sig) and all(_sig(t) == s for t, s in zip(ins, self.in_sig))
@@ -232,6 +241,9 @@ class BlockProgram:
         for t, e in zip(outs, self.out_ext):
             ptrs[e] = t.untyped_storage().data_ptr()
         arr = (ctypes.c_void_p * len(ptrs))(*ptrs)
+        if self.timing is not None:  # developer tool (tools/block_stage_times.py): per-stage timestamps of workgroup 0
+            L.check(L.lib().ey_block_run_timed(self.prog.data_ptr(), self.n, self.B, arr, len(ptrs), self.timing.data_ptr(), L.stream()), "ey_block_run_timed")
+            return outs
         with _ops._tr(f"block_kernel<{self.tag}>", self.alg_bytes, self.flops, note=f"{self.n} stages"):
             L.check(L.lib().ey_block_run(self.prog.data_ptr(), self.n, self.B, arr, len(ptrs), L.stream()), "ey_block_run")
         return outs

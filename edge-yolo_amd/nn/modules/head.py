@@ -49,8 +49,9 @@ class Detect(nn.Module):
     tower_streams = None
     chain = True
     #  block_fusion: both towers of a pyramid level whose map has at most block_max_pixels pixels (20x20 at 640x640) run as ONE block
-    #                program (nn/_block.py: one persistent workgroup per image) instead of 7 launches; f16 mode only
-    block_fusion = True
+    #                program (nn/_block.py: one persistent workgroup per image) instead of 7 launches; f16 mode only.  Opt-in: measured
+    #                slower than the per-layer kernels at batch 32 (see DetectionModel.block_fusion)
+    block_fusion = False
     block_max_pixels = 1024
 
     def __init__(self, nc=80, ch=()):

@@ -180,7 +180,10 @@ class BaseModel(nn.Module):
         return x, y
 
     # ---- block programs (nn/_block.py): runs of consecutive small-map layers as ONE launch -------------------------------------
-    block_fusion = True      # False: always the per-layer kernels
+    # Opt-in (default off): measured on MI355X at batch 32 the one-workgroup-per-image block programs cut the step from 116 to 76
+    # launches but run ~5x longer than the per-layer kernels they replace (a 1024-thread workgroup has 128 VGPRs per wave and one CU's
+    # 64 B/clk vector-memory path: profiles/r02_block_stage_times.txt) -- kept as a tested option, not the default
+    block_fusion = False
     block_max_pixels = 1024  # a run is block-executed while its first layer's output map has at most this many pixels (20x20 at 640x640)
 
     def _block_end(self, i, hi, x):

@@ -259,7 +259,7 @@ typedef struct {
   int32_t ngroup; int64_t src_g, y_g;   /* CONV: channel-offset groups as in ey_conv_desc */
   int32_t heads;               /* LINATTN: heads of 64 channels, even */
   /* filled by ey_block_compile */
-  int32_t kpad, nt_pack, mt, nti;
+  int32_t kpad, nt_pack, mt, nti, lds;
   float zsy, zsx;
 } ey_block_stage;
 size_t ey_block_stage_sizeof(void);
@@ -268,6 +268,9 @@ size_t ey_block_program_bytes(int nstages);
 int ey_block_compile(const ey_block_stage* stages_host, int nstages, void* out_host, size_t out_bytes);
 /* One launch: grid = B workgroups.  ext_ptrs_host: the `next` (<= 8) external tensors' device base pointers (host array, read at call time). */
 int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream);
+/* Developer tool: the same launch; workgroup 0 also stores wall_clock64() (100 MHz ticks) at the start and after every stage into
+ * tstamps_dev[nstages + 1] (tools/block_stage_times.py prints the per-stage split). */
+int ey_block_run_timed(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, long long* tstamps_dev, ey_stream_t stream);
 
 /* ---- K11: batched per-image NMS (non_max_suppression, utils/ops.py:230-316, and the torchvision.ops.nms it calls
  * at :296).  multi_label=0: best class per anchor (predict, ops.py:273-275); multi_label=1: one candidate per

@@ -1,5 +1,5 @@
-"""-m gpu: block programs (csrc/block.hip through nn/_block.py): the 20x20 layer runs of the network (layers 7-10 and 20-22 of the
-24-layer YAMLs, the 20x20 Detect towers) executed by ONE launch each.
+"""-m gpu: block programs (csrc/block.hip through nn/_block.py; opt-in, `block_fusion = True`): the 20x20 layer runs of the network
+(layers 7-10 and 20-22 of the 24-layer YAMLs, the 20x20 Detect towers) executed by ONE launch each.
 
 Every fused run is checked at its REAL shapes (640x640 input -> 20x20 maps): against the CPU oracle's per-layer outputs with the f16
 tolerance, and against the per-layer HIP kernels (same f16 rounding points -> tight agreement); stage-level unit tests cover each
@@ -94,6 +94,7 @@ def test_block_program_survives_weight_reload_and_graph_capture():
     """load_state_dict drops recorded programs (they hold packed weights); replay inside a captured hipGraph equals eager."""
     from edge_yolo_amd.engine.predictor import GraphRunner
     m, sd = _build("yolo11n-test.yaml")
+    m.block_fusion = m.model[-1].block_fusion = True
     x = synth.synth_images(2, 640, 640).cuda().half()
     y0 = m(x)[0].clone()
     sd2 = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=3)
