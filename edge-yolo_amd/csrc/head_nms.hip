@@ -398,6 +398,17 @@ struct NmsShared {
   KeptBox wbox[16][64];            // per wave: its 64 candidates' boxes (broadcast reads in the pairwise pass)
   unsigned long long wsup[16][64];  // per wave: bit i of wsup[j] = candidate i (earlier, alive) suppresses candidate j
   int sel_lo, cnt, nkept, processed;
+  // class-partitioned greedy (per-class NMS: candidates of different classes never interact, so wave w resolves the classes
+  // c % 16 == w on its own, with no workgroup barrier inside the suppression)
+  unsigned short order[1024];   // candidate indices of the chunk grouped by owner wave, score order inside a group
+  unsigned char keptflag[1024];
+  int wcnt[16][16];             // [wave][owner]: candidates of that owner in that wave's 64 (then: exclusive prefix over the waves)
+  int ototal[16], obase[16], npk[16], wtot2[16];
+  float wlo[16], whi[16];
+  int wbad[16];
+  float rmin, rmax;             // x extent of every candidate seen so far
+  int part;                     // 1 while the partitioned path is valid for this image
+  int part_chunk;               // ... and worth it for this chunk (no owner holds more than two 64-candidate rounds)
 };
 
 __device__ __forceinline__ void nms_block_suffix_scan(unsigned* h) {
@@ -448,7 +459,7 @@ __device__ __forceinline__ unsigned long long nms_sort1024(unsigned long long ke
 }
 
 __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
-                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap,
+                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
                                                                  int* __restrict__ out_index) {
@@ -467,7 +478,10 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
   unsigned long long prefix[6];
   hi[0] = 4096;
   prefix[0] = 0ull;
-  if (tid == 0) { S.nkept = 0; S.processed = 0; }
+  if (tid == 0) { S.nkept = 0; S.processed = 0; S.part = partition; S.rmin = INFINITY; S.rmax = -INFINITY; }
+  if (tid < 16) S.npk[tid] = 0;
+  unsigned short* pkl = reinterpret_cast<unsigned short*>(kept + max_det);  // [16][max_det]: ranks of the boxes each owner wave has kept so far
+  KeptBox* cbox = &S.wbox[0][0];                                             // [1024]: the chunk's candidate boxes (class offset applied)
   bool need_hist = true;
   __syncthreads();
 
@@ -584,6 +598,112 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
         x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
         area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
       }
+      if (partition && n <= 1024 && S.part) {
+        // ---- class-partitioned greedy.  Valid while all candidates seen so far span less than max_wh in x: boxes of different
+        // classes (offset by c * max_wh, ops.py:289) then cannot overlap, exactly as in the reference.
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        float lo = alive ? ux1 : INFINITY, hi = alive ? ux2 : -INFINITY;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+        const unsigned long long badm = __ballot(alive && !(ux1 == ux1 && ux2 == ux2));
+        if (lane == 0) { S.wlo[wave] = lo; S.whi[wave] = hi; S.wbad[wave] = badm != 0ull; }
+        cbox[tid] = KeptBox{x1, y1, x2, y2, area};
+        S.keptflag[tid] = 0;
+        const int owner = alive ? (ci & 15) : 16;
+        int myrank = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          const unsigned long long m = __ballot(owner == w);
+          if (lane == 0) S.wcnt[wave][w] = __popcll(m);
+          if (owner == w) myrank = __popcll(m & lt);
+        }
+        __syncthreads();
+        if (tid < 16) {  // owner `tid`: exclusive prefix of its counts over the waves
+          int run = 0;
+          for (int wv = 0; wv < 16; ++wv) { const int c = S.wcnt[wv][tid]; S.wcnt[wv][tid] = run; run += c; }
+          S.ototal[tid] = run;
+        }
+        if (tid == 32) {
+          float mn = S.rmin, mx = S.rmax;
+          int bad = 0;
+          for (int wv = 0; wv < 16; ++wv) { mn = fminf(mn, S.wlo[wv]); mx = fmaxf(mx, S.whi[wv]); bad |= S.wbad[wv]; }
+          S.rmin = mn; S.rmax = mx;
+          if (bad || !(__fsub_rn(mx, mn) < max_wh)) S.part = 0;  // (also catches NaN / inf extents)
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int run = 0, mx = 0;
+          for (int w = 0; w < 16; ++w) { S.obase[w] = run; run += S.ototal[w]; mx = max(mx, S.ototal[w]); }
+          // one dominant class would leave its wave to resolve everything alone (measured: 3x slower than the cooperative scan on the
+          // random-init model, whose arg-max class is nearly constant): take the partitioned path only for balanced chunks
+          S.part_chunk = S.part && mx <= 128;
+        }
+        __syncthreads();
+        if (S.part_chunk) {
+          if (alive) S.order[S.obase[owner] + S.wcnt[wave][owner] + myrank] = (unsigned short)tid;
+          __syncthreads();
+          {  // wave `wave` owns the classes c % 16 == wave: its candidates, in score order, 64 at a time; no workgroup barrier in here
+            const int base = S.obase[wave], tot = S.ototal[wave], npk = S.npk[wave];
+            const unsigned short* mypk = pkl + wave * max_det;
+            int nck = 0;
+            for (int t0 = 0; t0 < tot; t0 += 64) {
+              const bool on = t0 + lane < tot;
+              const int idx = on ? (int)S.order[base + t0 + lane] : 0;
+              __builtin_amdgcn_wave_barrier();
+              const KeptBox me = cbox[idx];
+              bool al = on;
+              for (int k = 0; k < npk; ++k) {  // boxes this owner kept in earlier chunks
+                const KeptBox kb = kept[mypk[k]];
+                al = al && !iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, me.x1, me.y1, me.x2, me.y2, me.area, iou_thres);
+              }
+              for (int k = 0; k < nck; ++k) {  // ... and earlier in this chunk (compacted to the front of its order[] segment)
+                const KeptBox kb = cbox[S.order[base + k]];
+                al = al && !iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, me.x1, me.y1, me.x2, me.y2, me.area, iou_thres);
+              }
+              unsigned long long mysup = 0ull;
+              const int nin = min(64, tot - t0);
+              for (int i = 0; i + 1 < nin; ++i) {  // pairwise inside the 64: bit i = "earlier candidate i overlaps me"
+                const KeptBox bi = cbox[__builtin_amdgcn_readlane(idx, i)];
+                if (i < lane && iou_gt(bi.x1, bi.y1, bi.x2, bi.y2, bi.area, me.x1, me.y1, me.x2, me.y2, me.area, iou_thres)) mysup |= 1ull << i;
+              }
+              const unsigned sup_lo = (unsigned)mysup, sup_hi = (unsigned)(mysup >> 32);
+              const unsigned long long am = __ballot(al);
+              unsigned long long keptm = 0ull;
+              for (unsigned long long mbits = am; mbits; mbits &= mbits - 1) {
+                const int j = __ffsll((unsigned long long)mbits) - 1;
+                const unsigned long long sj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)sup_hi, j) << 32) |
+                                              (unsigned)__builtin_amdgcn_readlane((int)sup_lo, j);
+                if ((sj & keptm) == 0ull) keptm |= 1ull << j;
+              }
+              if ((keptm >> lane) & 1ull) {
+                S.order[base + nck + __popcll(keptm & lt)] = (unsigned short)idx;
+                S.keptflag[idx] = 1;
+              }
+              nck += __popcll(keptm);
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          __syncthreads();
+          // kept candidates -> global ranks in score order (= chunk order), outputs, per-owner lists for the next chunk
+          const int nk0 = S.nkept;
+          const bool k_i = alive && S.keptflag[tid] != 0;
+          const unsigned long long km = __ballot(k_i);
+          if (lane == 0) S.wtot2[wave] = __popcll(km);
+          __syncthreads();
+          int before = nk0 + __popcll(km & lt), total = nk0;
+          for (int w = 0; w < 16; ++w) { const int c = S.wtot2[w]; total += c; if (w < wave) before += c; }
+          if (k_i && before < max_det) {
+            kept[before] = KeptBox{x1, y1, x2, y2, area};
+            float* ob = out_boxes + ((long)b * max_det + before) * 6;
+            ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
+            if (out_index) out_index[(long)b * max_det + before] = a;
+            pkl[owner * max_det + atomicAdd(&S.npk[owner], 1)] = (unsigned short)before;
+          }
+          __syncthreads();
+          if (tid == 0) S.nkept = min(max_det, total);
+          continue;
+        }
+      }
       // pairwise pass, all 16 waves at once: bit i of mysup = "earlier candidate i of my wave overlaps me beyond the
       // threshold" (independent of who survives; survival is applied in the scan below)
       S.wbox[wave][lane] = KeptBox{x1, y1, x2, y2, area};
@@ -639,6 +759,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
             float* ob = out_boxes + ((long)b * max_det + rank) * 6;
             ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
             if (out_index) out_index[(long)b * max_det + rank] = a;
+            if (partition) pkl[(ci & 15) * max_det + atomicAdd(&S.npk[ci & 15], 1)] = (unsigned short)rank;  // (a later chunk may run class-partitioned)
           }
           if (lane == 0) S.nkept = min(max_det, nk + __popcll(keptm));
         }
@@ -665,13 +786,15 @@ extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size
 static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
                              float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
                              hipStream_t st) {
-  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox);
+  const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
+  // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
+  const int partition = !agnostic && nc > 1 && cap == 1024;
+  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0);
   EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
-  const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
   hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
-                     target, cap, keys, cls_id, out_boxes, out_count, out_index);
+                     target, cap, partition, keys, cls_id, out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }

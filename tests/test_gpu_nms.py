@@ -108,6 +108,31 @@ def test_heavy_bin_exhausted_subtree(ops):
             np.testing.assert_array_equal(boxes[b, :n].cpu().numpy(), want[b])
 
 
+@pytest.mark.parametrize("max_wh", [100.0, 700.0, 7680.0])
+def test_class_partitioned_greedy_and_its_fallback(ops, max_wh):
+    """Per-class NMS runs class-partitioned (wave w resolves the classes c % 16 == w with no workgroup barrier).  That is only valid
+    while boxes of different classes cannot overlap after the c * max_wh offset (ops.py:289); with a small max_wh they do overlap in the
+    reference, and the kernel must notice and fall back to the cooperative scan.  Heavy same-class overlap (many chunks, persistent
+    per-owner lists), 40 classes (several classes per wave), rows and indices bit-exact in all three regimes."""
+    rng = np.random.default_rng(11)
+    B, nc, A = 3, 40, 6000
+    pred = np.zeros((B, 4 + nc, A), np.float32)
+    for b in range(B):
+        centres = rng.uniform(40, 600, (150, 2))
+        which = rng.integers(0, 150, A)
+        pred[b, 0:2] = (centres[which] + rng.normal(0, 4.0, (A, 2))).T
+        pred[b, 2:4] = rng.lognormal(np.log(50.0), 0.25, (2, A))
+        cls = (which * 7 + rng.integers(0, 2, A)) % nc  # a cluster holds two classes
+        pred[b, 4 + cls, np.arange(A)] = rng.uniform(0.26, 0.99, A)
+    want, widx = onms.non_max_suppression(pred, 0.25, 0.6, max_det=300, max_wh=max_wh, return_idx=True)
+    boxes, count, index = ops.nms_device(torch.tensor(pred).cuda(), 0.25, 0.6, max_det=300, max_wh=max_wh)
+    for b in range(B):
+        n = int(count[b])
+        assert n == want[b].shape[0] and n > 50
+        np.testing.assert_array_equal(index[b, :n].cpu().numpy(), widx[b])
+        np.testing.assert_array_equal(boxes[b, :n].cpu().numpy(), want[b])
+
+
 def test_argument_errors(ops):
     pred = synth.synth_pred(1, 4, 64, seed=1).cuda()
     with pytest.raises(AssertionError):
