@@ -1255,6 +1255,10 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(ConvP p, ChainP q) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = ey_act(acc2[nt][j] + b2[4 * nt + j], q.act2);
           store4(yp + 4 * nt, v);
+        } else {  // channel tail (Cout not a multiple of 4, e.g. nc = 10)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (ch2 + 4 * nt + j < q.Cout2) yp[4 * nt + j] = (T)ey_act(acc2[nt][j] + b2[4 * nt + j], q.act2);
         }
       }
     }
@@ -1937,9 +1941,14 @@ extern "C" int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmi
   EY_CHECK(dtype == EY_F16, "conv_pw_chain: f16 only");
   EY_CHECK(x && w1_packed && w2_packed && y && B > 0 && H > 0 && W > 0, "conv_pw_chain: bad arguments");
   const int nt1 = conv_nt(Cmid), nt2 = conv_nt(Cout), ks1 = (Cin + 31) / 32;
-  if (!(nt1 == 5 && Cmid == 80 && nt2 == 5 && Cout <= 80 && Cout % 4 == 0 && ks1 == 3 && Cin % 8 == 0))
-    return ey_set_error(EY_EUNSUPPORTED, "conv_pw_chain: built for Cin 72..96 -> 80 -> <= 80 (got %d -> %d -> %d)", Cin, Cmid, Cout);
+  // two shapes of the Detect class tower (head.py:59,68-70; c3 = max(ch[0], min(nc, 100))): nc = 80 -> 80 -> 80 -> 80, and small class
+  // counts (GC10-DET, nc = 10: c3 = 64) -> 64 -> 64 -> nc <= 16
+  const bool wide = nt1 == 5 && Cmid == 80 && nt2 == 5 && Cout <= 80 && Cout % 4 == 0 && ks1 == 3 && Cin % 8 == 0;
+  const bool narrow = nt1 == 4 && Cmid == 64 && nt2 == 1 && Cout >= 1 && Cout <= 16 && ks1 == 2 && Cin % 8 == 0;
+  if (!wide && !narrow)
+    return ey_set_error(EY_EUNSUPPORTED, "conv_pw_chain: built for Cin 72..96 -> 80 -> <= 80 and Cin 40..64 -> 64 -> <= 16 (got %d -> %d -> %d)", Cin, Cmid, Cout);
   EY_CHECK(x_cstride >= Cin && (x_cstride * 2) % 16 == 0 && ey_aligned(x, 16) && y_cstride >= Cout && (y_cstride * 2) % 8 == 0 && ey_aligned(y, 8), "conv_pw_chain: view alignment");
+  (void)0;
   const long M = (long)B * H * W, bytes = ((M - 1) * x_cstride + Cin) * 2L;
   EY_CHECK(bytes < (1L << 31) && M < (1L << 27), "conv_pw_chain: tensor too large");
   ConvP p;
@@ -1948,7 +1957,7 @@ extern "C" int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmi
   p.w = w1_packed; p.bias = b1; p.Kpad = conv_kpad(Cin, 1); p.ntile = (M + 15) / 16;
   ChainP q;
   q.w2 = w2_packed; q.b2 = b2; q.act2 = act2; q.Cout2 = Cout; q.Kpad2 = conv_kpad(ey_conv_chain_klen(Cmid), 1); q.y2 = y; q.y2Cs = y_cstride;
-  return pw2_launch<5, 3, 5>(p, q, (hipStream_t)stream);
+  return wide ? pw2_launch<5, 3, 5>(p, q, (hipStream_t)stream) : pw2_launch<4, 2, 1>(p, q, (hipStream_t)stream);
 }
 
 // Which kernel instantiation ey_conv2d launches for a shape (profiling / documentation only): kind*1000 + NT*10 + MT,

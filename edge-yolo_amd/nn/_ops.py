@@ -209,7 +209,7 @@ def conv_pw_chain(mod, x, fold1, act1, fold2, act2, out):
         w2, b2 = fold2()
         cmid, cout = w1.shape[0], w2.shape[0]
         klen = L.lib().ey_conv_chain_klen(cmid)
-        if not klen or w1.shape[2] != 1 or w2.shape[2] != 1 or w2.shape[1] != cmid or not (cmid == 80 and 64 < cout <= 80 and cout % 4 == 0 and 72 <= cin <= 96):
+        if not klen or w1.shape[2] != 1 or w2.shape[2] != 1 or w2.shape[1] != cmid or not ((cmid == 80 and 64 < cout <= 80 and cout % 4 == 0 and 72 <= cin <= 96) or (cmid == 64 and 1 <= cout <= 16 and 40 <= cin <= 64)):
             return False  # cached: this pair runs as two convs
         perm = (ctypes.c_int * klen)()
         L.check(L.lib().ey_conv_chain_kperm(cmid, perm, klen), "ey_conv_chain_kperm")

@@ -107,7 +107,8 @@ int ey_conv_last_variant(void);
  * of the Detect class tower (Conv(c3,c3,1)+SiLU, nn.Conv2d(c3,nc,1); head.py:68-70).  w1_packed = ey_conv_pack_weight(Cmid, Cin, 1);
  * w2_packed = ey_conv_pack_weight(Cout, ey_conv_chain_klen(Cmid), 1) of W2 with its INPUT columns gathered by ey_conv_chain_kperm
  * (perm[k'] = mid channel feeding k-slot k', -1 = zero column): the second contraction runs in the order the first GEMM leaves its
- * results in the registers.  f16 only; built for Cin 72..96, Cmid = 80, Cout <= 80; EY_EUNSUPPORTED otherwise (run the two convs). */
+ * results in the registers.  f16 only; built for the two class-tower shapes Cin 72..96 -> Cmid 80 -> Cout <= 80 (nc = 80) and Cin 40..64 ->
+ * Cmid 64 -> Cout <= 16 (small class counts, e.g. GC10-DET nc = 10); EY_EUNSUPPORTED otherwise (run the two convs). */
 int ey_conv_chain_klen(int Cmid);
 int ey_conv_chain_kperm(int Cmid, int* perm_host, int perm_len);
 int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmid, int Cout, const void* x, int x_cstride, const void* w1_packed,

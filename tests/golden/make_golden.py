@@ -30,13 +30,14 @@ from ultralytics.utils import ops as rops, tal as rtal  # noqa: E402
 from ultralytics.utils.torch_utils import fuse_conv_and_bn  # noqa: E402
 
 torch.set_grad_enabled(False)
+LARGE_GAIN = 1.0  # l / x scales are twice as deep: the default conv gain (1.9) lets activations grow to ~1e4 there; 1.0 keeps them O(10)
 YAMLS = ["yolo11", "yolo11-test", "yolo11-tune", "yolo11-lineattention", "yolo11-DSC3K2_Wavelet", "yolo11-GF2Detect"]
 
 
-def build(name, nc=80):
+def build(name, nc=80, gain=1.9):
     m = DetectionModel(name, ch=3, nc=nc, verbose=False).eval()
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
-    m.load_state_dict(synth.synth_state_dict(shapes))
+    m.load_state_dict(synth.synth_state_dict(shapes, gain=gain))
     return m, shapes
 
 
@@ -68,8 +69,8 @@ HOOKS = {  # inner modules whose outputs pin the per-op restatements
 }
 
 
-def model_small(name, tag, b=2, h=64, w=64, layers=True):
-    m, _ = build(name)
+def model_small(name, tag, b=2, h=64, w=64, layers=True, gain=1.9):
+    m, _ = build(name, gain=gain)
     m.fuse(verbose=False)
     d = {}
     mods = dict(m.named_modules())
@@ -94,7 +95,7 @@ def model_640(name, tag, h=640, w=640, step=7):
     d = dict(y_sub=y[:, :, ::step].numpy(), step=np.int64(step), row_sum=y.double().sum(-1).numpy(),
              row_abs=y.double().abs().sum(-1).numpy())
     # the full predict-time post-process on the same output (conf .25, iou .7: cfg/default.yaml:51-65)
-    det = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300)
+    det = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, max_time_img=1e6)
     d["det0"] = det[0].numpy()
     np.savez_compressed(os.path.join(HERE, f"{tag}.npz"), **d)
     print(tag, y.shape, det[0].shape)
@@ -154,7 +155,9 @@ def nms_cases():
     d, meta = {}, {}
 
     def run(tag, pred, **kw):
-        out = rops.non_max_suppression(pred.clone(), **kw)
+        # max_time_img: the reference aborts NMS on a wall-clock limit (ops.py:238,312-314); with the slow numpy stand-in for
+        # torchvision.ops.nms that limit could truncate a multi-image case on a slow box -> neutralised (not part of the stored kwargs)
+        out = rops.non_max_suppression(pred.clone(), max_time_img=1e6, **kw)
         meta[tag] = dict(kw=kw, n=[int(o.shape[0]) for o in out])
         for i, o in enumerate(out):
             d[f"{tag}_{i}"] = o.numpy()
@@ -230,7 +233,71 @@ def metrics_cases():
     print("metrics", out[5].mean())
 
 
+def validator_case():
+    """End-to-end validation fixture from REAL model outputs: reference EdgeLine-n forward on 6 letterboxed synthetic images ->
+    reference validation-mode NMS -> labels = jittered copies of confident detections (in the dataset's collate format, with
+    ori_shape / ratio_pad) -> the reference's own DetectionValidator.update_metrics / get_stats / DetMetrics."""
+    import types
+    from ultralytics.models.yolo.detect.val import DetectionValidator as RV
+    from ultralytics.utils import metrics as rm
+    m, _ = build("yolo11n-test.yaml")
+    m.fuse(verbose=False)
+    B, H, W = 6, 128, 160
+    x = synth.synth_images(B, H, W, seed=9)
+    y, _ = m(x)
+    preds = rops.non_max_suppression(y.clone(), 0.001, 0.7, multi_label=True, max_det=300, max_time_img=1e6)
+    r = np.random.default_rng(5)
+    ori = [(100, 160), (128, 128), (256, 320), (128, 160), (90, 120), (64, 80)]
+    ratio_pad = []
+    for h0, w0 in ori:  # LetterBox geometry (data/augment.py:1556-1591) as the dataset records it
+        g = min(H / h0, W / w0)
+        nw, nh = round(w0 * g), round(h0 * g)
+        dw, dh = (W - nw) / 2, (H - nh) / 2
+        ratio_pad.append(((g, g), (int(round(dw - 0.1)), int(round(dh - 0.1)))))
+    cls, box, bidx = [], [], []
+    for i, p in enumerate(preds):
+        k = [3, 0, 5, 2, 4, 1][i]
+        for j in r.permutation(min(len(p), 40))[:k]:
+            b = p[j, :4].numpy() + r.normal(0, 2.0, 4)
+            c = float(p[j, 5]) if r.random() < 0.8 else float(r.integers(0, 80))
+            cls.append([c]); bidx.append(i)
+            box.append([(b[0] + b[2]) / 2 / W, (b[1] + b[3]) / 2 / H, abs(b[2] - b[0]) / W, abs(b[3] - b[1]) / H])
+    batch = dict(img=x, cls=torch.tensor(cls, dtype=torch.float32), bboxes=torch.tensor(np.array(box), dtype=torch.float32),
+                 batch_idx=torch.tensor(bidx, dtype=torch.float32), ori_shape=ori, ratio_pad=ratio_pad, im_file=[f"im{i}.jpg" for i in range(B)])
+
+    class V(RV):
+        def __init__(self):  # the validator's own set-up needs a dataset / cfg; only the metric plumbing is exercised
+            pass
+    v = V()
+    v.device = torch.device("cpu")
+    v.args = types.SimpleNamespace(single_cls=False, plots=False, save_json=False, save_txt=False, save_conf=False)
+    v.iouv = torch.linspace(0.5, 0.95, 10)
+    v.niou, v.nc, v.seen = 10, 80, 0
+    v.names = {i: str(i) for i in range(80)}
+    v.metrics = rm.DetMetrics(names=v.names)
+    v.stats = dict(tp=[], conf=[], pred_cls=[], target_cls=[], target_img=[])
+    v.confusion_matrix = None
+    v.update_metrics([p.clone() for p in preds], batch)
+    tp = torch.cat(v.stats["tp"], 0).numpy()
+    res = v.get_stats()
+    d = dict(cls=batch["cls"].numpy(), bboxes=batch["bboxes"].numpy(), batch_idx=batch["batch_idx"].numpy(), ori_shape=np.array(ori),
+             ratio_gain=np.array([rp[0][0] for rp in ratio_pad]), ratio_padwh=np.array([rp[1] for rp in ratio_pad]), tp=tp,
+             keys=np.array(list(res.keys())), values=np.array([float(v_) for v_ in res.values()]), seen=np.int64(v.seen),
+             nt_per_class=v.nt_per_class, ap=v.metrics.box.all_ap, ap_class_index=np.asarray(v.metrics.box.ap_class_index))
+    for i, p in enumerate(preds):
+        d[f"pred{i}"] = p.numpy()
+    np.savez_compressed(os.path.join(HERE, "validator_case.npz"), **d)
+    print("validator", dict(res), "tp", int(tp.sum()), "labels", len(cls))
+
+
 if __name__ == "__main__":
+    if "--validator-only" in sys.argv:
+        validator_case()
+        sys.exit(0)
+    if "--large-only" in sys.argv:
+        model_small("yolo11l-test.yaml", "edgeline_l_64", b=1, layers=False, gain=LARGE_GAIN)
+        model_small("yolo11x.yaml", "yolo11x_64", b=1, layers=False, gain=LARGE_GAIN)
+        sys.exit(0)
     metrics_cases() if "--metrics-only" in sys.argv else None
     if "--metrics-only" in sys.argv:
         sys.exit(0)
@@ -238,10 +305,14 @@ if __name__ == "__main__":
     ops_small()
     nms_cases()
     metrics_cases()
+    validator_case()
     model_small("yolo11n-test.yaml", "edgeline_n_64")
     model_small("yolo11n.yaml", "yolo11n_64")
     for abl in ("GF2Detect", "lineattention", "DSC3K2_Wavelet", "tune"):
         model_small(f"yolo11n-{abl}.yaml", f"{abl.lower()}_n_64", b=1, layers=False)
     model_small("yolo11n-test.yaml", "edgeline_n_96x160", b=1, h=96, w=160, layers=False)
+    # l / x scales force c3k=True inside C3k2 / DSC3K2_Wavelet (tasks.py:1069-1072) and use depth > 1: other module paths than n/s/m
+    model_small("yolo11l-test.yaml", "edgeline_l_64", b=1, layers=False, gain=LARGE_GAIN)
+    model_small("yolo11x.yaml", "yolo11x_64", b=1, layers=False, gain=LARGE_GAIN)
     model_640("yolo11n-test.yaml", "edgeline_n_640")
     model_640("yolo11n.yaml", "yolo11n_640")

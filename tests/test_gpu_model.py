@@ -19,11 +19,11 @@ def E():
     return edge_yolo_amd
 
 
-def _build(E, name, dtype):
+def _build(E, name, dtype, gain=1.9):
     from edge_yolo_amd.nn.tasks import DetectionModel
     m = DetectionModel(name)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
-    sd = synth.synth_state_dict(shapes)
+    sd = synth.synth_state_dict(shapes, gain=gain)
     m.load_state_dict(sd)
     m = m.to("cuda")
     m.fuse()
@@ -314,3 +314,68 @@ def test_fused_candidates_equal_nms_on_pred(E, name, nc):
                 assert torch.equal(g, w)
     with pytest.raises(ValueError):
         ops.nms_device(cand, 0.3, 0.6)  # candidates were built for another threshold
+
+
+@pytest.mark.parametrize("half,tol", [(False, 0.02), (True, 0.06)])
+def test_validator_end_to_end_vs_reference(E, golden_dir, half, tol):
+    """§8(f-1) end to end on the GPU: HIP model -> validation-mode NMS on the device -> DetectionValidator (label / ratio_pad scaling,
+    per-image stats, AP) against the mAP the REFERENCE got for the same images and labels with ITS model, NMS and validator
+    (tests/golden/validator_case.npz).  fp32 predictions agree to ~1e-3, so the statistics may differ by a few borderline matches."""
+    from edge_yolo_amd.engine.validator import DetectionValidator, KEYS
+    g = np.load(os.path.join(golden_dir, "validator_case.npz"))
+    m, _ = _build(E, "yolo11n-test.yaml", torch.float16 if half else torch.float32)
+    B = len(g["ori_shape"])
+    batch = {"img": synth.synth_images(B, 128, 160, seed=9), "cls": g["cls"], "bboxes": g["bboxes"], "batch_idx": g["batch_idx"],
+             "ori_shape": [tuple(s) for s in g["ori_shape"]],
+             "ratio_pad": [((float(a), float(a)), (int(p[0]), int(p[1]))) for a, p in zip(g["ratio_gain"], g["ratio_padwh"])]}
+    v = DetectionValidator(m, half=half)
+    res = v([batch])
+    ref = dict(zip(list(g["keys"]), g["values"]))
+    print(f"\\n[validator half={half}] ours {[round(res[k], 4) for k in KEYS]} reference {[round(float(ref[k]), 4) for k in KEYS]}")
+    assert v.seen == int(g["seen"])
+    np.testing.assert_array_equal(v.nt_per_class, g["nt_per_class"])
+    for k in (KEYS[2], KEYS[3], KEYS[4], KEYS[1]):
+        assert abs(res[k] - float(ref[k])) <= tol, (k, res[k], float(ref[k]))
+    if not half:  # same number of predictions per image as the reference produced
+        assert [len(t) for t in v.stats["tp"]] == [len(g[f"pred{i}"]) for i in range(B)]
+        assert abs(int(np.concatenate(v.stats["tp"]).sum()) - int(g["tp"].sum())) <= 6
+
+
+@pytest.mark.parametrize("name,tag", [("yolo11l-test.yaml", "edgeline_l_64"), ("yolo11x.yaml", "yolo11x_64")])
+def test_fp32_large_scales_vs_reference_golden(E, golden_dir, name, tag):
+    """l / x scales (c3k=True DSC3k / C3k inner blocks, 2 repeats per stage, up to 512-channel maps, 8-head attention at x)
+    on the GPU against the REFERENCE's forward (tests/golden, fp32, north-star bar 1e-3)."""
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    m, _ = _build(E, name, torch.float32, gain=1.0)  # make_golden.py LARGE_GAIN
+    y, raw = m(synth.synth_images(1, 64, 64).cuda())
+    np.testing.assert_allclose(y.cpu().numpy(), g["y"], rtol=1e-4, atol=1e-3)
+    for i, r in enumerate(raw):
+        np.testing.assert_allclose(r.float().cpu().numpy(), g[f"raw{i}"], rtol=1e-4, atol=3e-4)
+    yh, _ = _build(E, name, torch.float16, gain=1.0)[0](synth.synth_images(1, 64, 64).cuda().half())  # the f16 kernels take these widths too
+    assert float((yh[:, 4:].cpu() - torch.tensor(g["y"][:, 4:])).abs().max()) < 2e-2
+
+
+def test_nc10_model_and_chain_vs_oracle(E, cfg_dir):
+    """GC10-DET class count (nc = 10: c3 = 64, head.py:59): fp32 vs the oracle, and the f16 class tower through the 64 -> 64 -> 10
+    register chain (ey_conv_pw_chain narrow shape, scalar channel tail) vs the same model with the chain off."""
+    from edge_yolo_amd.nn.tasks import DetectionModel
+    from edge_yolo_amd import profiling
+    name = "yolo11n-test.yaml"
+    m = DetectionModel(name, nc=10)
+    sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()})
+    m.load_state_dict(sd)
+    x = synth.synth_images(2, 160, 160)
+    want, _ = om.OracleModel(os.path.join(cfg_dir, name), sd, nc=10)(x)
+    m32 = m.cuda().fuse().float().eval()
+    y32, _ = m32(x.cuda())
+    assert tuple(y32.shape) == (2, 14, 525)
+    np.testing.assert_allclose(y32.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-3)
+    mh = m32.half()
+    with profiling.trace() as t:
+        y_chain, _ = mh(x.cuda().half())
+    assert sum(r[0] == "conv_pw2_kernel" for r in t.records) == 3, "the narrow class-tower chain did not run"
+    mh.model[-1].chain = False
+    y_plain, _ = mh(x.cuda().half())
+    torch.cuda.synchronize()
+    assert float((y_chain[:, 4:] - y_plain[:, 4:]).abs().max()) < 2e-3 and float((y_chain[:, :4] - y_plain[:, :4]).abs().max()) < 0.25
+    assert float((y_chain[:, 4:].cpu() - want[:, 4:]).abs().max()) < 2e-2

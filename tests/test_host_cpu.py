@@ -203,3 +203,39 @@ def test_tunables_are_api_not_environment():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert "getenv" not in src and "os.environ" not in src, f"{f} reads the environment"
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/ultralytics"), reason="needs the reference package (build container only)")
+def test_reference_checkpoint_bridge(tmp_path):
+    """§8f-3: a checkpoint as the REFERENCE trainer writes it (pickled module, engine/trainer.py:513-546) -> tools/export_reference_weights.py
+    (runs where the reference is importable) -> tensor-only file -> YOLO(path): same YAML, nc, every tensor equal."""
+    import subprocess
+    import sys
+    ref_pt, out_pt = str(tmp_path / "ref_best.pt"), str(tmp_path / "bridge.pt")
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.join(ROOT, 'tests', 'golden')!r}); sys.path.insert(0, {ROOT!r})
+import _ref_import; _ref_import.setup()
+import torch, synthdata as synth
+from ultralytics.nn.tasks import DetectionModel
+m = DetectionModel('yolo11n-test.yaml', ch=3, nc=10, verbose=False)
+m.load_state_dict(synth.synth_state_dict({{k: tuple(v.shape) for k, v in m.state_dict().items()}}))
+torch.save({{'epoch': 3, 'model': None, 'ema': m.half(), 'train_args': {{}}}}, {ref_pt!r})   # the trainer's checkpoint layout
+sys.path.insert(0, {os.path.join(ROOT, 'tools')!r})
+import export_reference_weights as ex
+print(ex.export({ref_pt!r}, {out_pt!r}))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ck = torch.load(out_pt, weights_only=True)  # tensor-only: the safe loader reads it
+    assert ck["nc"] == 10 and ck["fused"] is False and isinstance(ck["yaml"], dict)
+    y = edge_yolo_amd.YOLO(out_pt)
+    assert y.model.model[-1].nc == 10
+    want = synth.synth_state_dict({k: tuple(v.shape) for k, v in y.model.state_dict().items()})
+    got = y.model.state_dict()
+    assert set(got) == set(ck["state_dict"])
+    for k, v in want.items():
+        if v.is_floating_point():  # the checkpoint was the trainer's half-precision EMA: values are the f16-rounded synthetic weights
+            torch.testing.assert_close(got[k].float(), v.half().float(), rtol=0, atol=0)
+        else:
+            assert torch.equal(got[k], v)

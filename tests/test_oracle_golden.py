@@ -169,3 +169,19 @@ def test_nms_cases(golden_dir):
         assert [o.shape[0] for o in out] == m["n"], tag
         for i, o in enumerate(out):
             np.testing.assert_array_equal(o, g[f"{tag}_{i}"], err_msg=tag)  # bit-exact
+
+
+@pytest.mark.parametrize("name,tag", [("yolo11l-test.yaml", "edgeline_l_64"), ("yolo11x.yaml", "yolo11x_64")])
+def test_model_large_scales(cfg_dir, golden_dir, name, tag):
+    """l / x scales (c3k forced True inside C3k2 / DSC3K2_Wavelet, tasks.py:1069-1072; repeats > 1): the oracle against the reference's
+    forward.  (Weights are synthesised by name from the product's state_dict shapes; structure.json pins those for scale n and the
+    graph for l.)"""
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd.nn.tasks import DetectionModel
+    g = _load(golden_dir, tag)
+    shapes = {k: tuple(v.shape) for k, v in DetectionModel(name).state_dict().items()}
+    o = om.OracleModel(os.path.join(cfg_dir, name), synth.synth_state_dict(shapes, gain=1.0))  # make_golden.py LARGE_GAIN
+    y, raw = o.forward(synth.synth_images(1, 64, 64))
+    torch.testing.assert_close(y, g["y"], rtol=1e-4, atol=2e-4)
+    for i, r in enumerate(raw):
+        torch.testing.assert_close(r, g[f"raw{i}"], **TOL)
