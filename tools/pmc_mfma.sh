@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 T=$1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmcm_$T -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-pipeline > $R/gpurun_out/pmcm_$T.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE -d $R/gpurun_out/pmcm_$T -o p --output-format csv -- python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-api --no-pipeline > $R/gpurun_out/pmcm_$T.log 2>&1
 python3 - $(find $R/gpurun_out/pmcm_$T -name "*counter_collection.csv" | head -1) $R/gpurun_out/${T}_pmc_mfma.csv <<'PY'
 import collections, csv, sys
 sys.path.insert(0, sys.argv[0] and '.')

@@ -3,9 +3,13 @@ profiles/<tag>_pmc_traffic.json, keyed by the kernel labels bench.py's `roofline
 usage: traffic_from_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
 
 Units / corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are KB per dispatch (derived from
-TCC_EA0_RDREQ / WRREQ); on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of wide (16 B/lane) coalesced streaming reads,
-so it is doubled here (all heavy kernels of this path read with 16-byte buffer/global loads); WRITE_SIZE is exact for
-16-byte stores.  Infinity-Cache hits are counted, i.e. this is traffic at the L2's memory side, not DRAM-only."""
+TCC_EA0_RDREQ / WRREQ: 128-byte memory-side requests tallied at 64 B); the guide documents the factor 2 for 16 B/lane streaming
+reads and calls other widths uncalibrated, so it was CALIBRATED here (tools/micro/fetch_calib.hip, profiles/r02_fetch_size_calibration.txt):
+bytes / FETCH_SIZE = 2.000 for fully coalesced streaming reads of 16, 8, 4 AND 2 bytes per lane -- the factor belongs to the
+memory-side request size, not to the lane width -- so every kernel's FETCH_SIZE is doubled.  What the doubled figure counts is whole
+128-byte lines: a kernel that touches partial lines fetches more than its useful bytes (288-byte row segments at a 1280-byte pitch,
+the MFMA stem's patch rows: 1.36x the useful bytes).  WRITE_SIZE is exact for 16-byte stores.  Infinity-Cache hits are counted,
+i.e. this is traffic at the L2's memory side, not DRAM-only."""
 import collections
 import csv
 import json
@@ -54,8 +58,16 @@ def label_of(name):
     for k in ("stem_kernel", "dwt_kernel", "head_decode_kernel", "linattn_kernel", "sppf_kernel", "copy_kernel", "softattn_kernel"):
         if k in name:
             return k
+    if "nms_select" in name:
+        return "nms_select_greedy_kernel"
     if "nms_" in name:
         return "nms(score+sort_greedy)"
+    if "block_kernel" in name:
+        return "block_kernel"
+    if "conv_pw2" in name:
+        return "conv_pw2_kernel"
+    if "linattn_mfma" in name:
+        return "linattn_kernel"
     return None
 
 
@@ -81,6 +93,7 @@ if __name__ == "__main__":
         write = 1024 * kw / max(nw, 1)
         out[lab] = {"launches_profiled": nf, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                     "hbm_bytes_per_launch": round(fetch + write), "fetch_kb_raw_avg": round(kf / max(nf, 1), 1)}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-pipeline; FETCH_SIZE doubled (gfx950 wide-read correction)",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-pipeline; FETCH_SIZE x 2 = 128-byte lines fetched "
+                         "(calibrated for 2/4/8/16 B per lane coalesced reads: profiles/r02_fetch_size_calibration.txt)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(f"{len(out)} kernels -> {sys.argv[3]}")
