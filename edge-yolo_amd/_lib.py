@@ -82,6 +82,7 @@ SIGNATURES = {
     "ey_dsconv_tz": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dsconv_last_variant": (_i, []),
     "ey_dwt_haar": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "ey_wavelet_z": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, C.c_long, _vp, _vp, _vp, _i, _vp]),
     "ey_sppf_pool": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "ey_copy_nhwc": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ey_nchw_to_nhwc": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),

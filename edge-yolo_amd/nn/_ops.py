@@ -386,6 +386,33 @@ def dwt_haar(x, out=None):
     return out
 
 
+def wavelet_z(mod, b, sets_fn, z_fn):
+    """Half-resolution branch of _WaveletEnhancer in ONE kernel (ey_wavelet_z): b (B,c,H,W) -> Z (B,c,H/2,W/2).  sets_fn() ->
+    ((w_ll3x3, b_ll), (w_h, b_h)) BN-folded fp32; z_fn() -> (w_z (c,2c,1,1), None).  Returns None when the shape is outside the fused
+    kernel (fp32 mode, c not in {16,32,64,128}, while a block program is recorded): the caller runs dwt + the two convs."""
+    L.require_device(b, "wavelet_z")
+    b = L.as_nhwc(b)
+    B, c, H, W = b.shape
+    if RECORD is not None or b.dtype != torch.float16 or c not in (16, 32, 64, 128) or H < 2 or W < 2 or (L.cstride(b) * 2) % 16 or b.data_ptr() % 16:
+        return None
+
+    def build():
+        (wl, bl), (wh, bh) = sets_fn()
+        wz, _ = z_fn()
+        packs = [pack_conv_weight(w, b.dtype, b.device) for w in (wl, wh)]
+        return (torch.cat(packs), packs[0].numel() // 2, torch.cat([bl.to(b.device).float(), bh.to(b.device).float()]).contiguous(),
+                pack_conv_weight(wz, b.dtype, b.device))
+
+    wsub, wset, bias, wz = mod._packed(_dev_key(b, "wavelet_z"), build)
+    z = L.empty_nhwc(B, c, H // 2, W // 2, b.dtype, b.device)
+    M = B * (H // 2) * (W // 2)
+    flops = 2.0 * M * ((c // 2) * c + 3 * (c // 2) * 9 * c + c * 2 * c) + 4.0 * b.numel()
+    with _tr("wavelet_z_kernel", _nb(b, z) + ((c // 2) * 10 * c + 2 * c * c) * 2, flops, note=f"C{c} {H}x{W}"):
+        L.check(L.lib().ey_wavelet_z(L.dtype_code(b.dtype), B, H, W, c, b.data_ptr(), L.cstride(b), wsub.data_ptr(), wset, bias.data_ptr(), wz.data_ptr(),
+                                     z.data_ptr(), L.cstride(z), L.stream()), "ey_wavelet_z")
+    return z
+
+
 def sppf_pool(x, y1, y2, y3):
     L.require_device(x, "sppf_pool")
     B, c, H, W = x.shape

@@ -308,6 +308,8 @@ class _WaveletEnhancer(_Packed):
     scale folded into its weights) whose bilinear x2 upsample is added before the activation in the epilogue of the
     full-resolution 1x1 conv over b, which also applies tanh(gamma) and the residual b."""
 
+    fused_z = True  # f16: the half-resolution branch as one kernel (ey_wavelet_z); False = dwt + 4-group conv + 1x1 conv (three launches)
+
     def __init__(self, c, use_ds=False, alpha0=(0.5, 0.2, 0.2, 0.1), wave="haar", mode="symmetric"):
         super().__init__()
         self.c = c
@@ -350,6 +352,11 @@ class _WaveletEnhancer(_Packed):
         if isinstance(self.f_h, DSConv):
             raise NotImplementedError("use_ds=True sub-band path is not built (no YAML enables it)")
         h = c // 2
+        g = self._packed("tanh_gamma", lambda: float(torch.tanh(self.gamma.detach().float())))  # host scalar, cached (graph capture)
+        if self.fused_z:  # f16: DWT + the four sub-band convs + Z in ONE kernel, only Z touches HBM
+            Z = ops.wavelet_z(self, b, self._subband_sets, self._fuse_z)
+            if Z is not None:
+                return ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")
         sub = ops.dwt_haar(b)  # (B,4c,H/2,W/2): LL|LH|HL|HH
         P = L.empty_nhwc(B, 2 * c, H // 2, W // 2, b.dtype, b.device)
         # ONE launch for the four sub-band convs: group 0 = f_ll (a 1x1 conv written as a centre-tap 3x3) on LL, groups 1-3 =
@@ -357,7 +364,6 @@ class _WaveletEnhancer(_Packed):
         ops.conv2d(self, [sub[:, :c]], self._subband_sets, 3, 1, 1, L.ACT_SILU, out=P[:, :h], ngroup=4, src_gstride=c, y_gstride=h, w_sets=2,
                    tag="sub")
         Z = ops.conv2d(self, [P], self._fuse_z, 1, 1, 0, L.ACT_NONE, tag="z")
-        g = self._packed("tanh_gamma", lambda: float(torch.tanh(self.gamma.detach().float())))  # host scalar, cached (graph capture)
         return ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")
 
 

@@ -167,6 +167,16 @@ int ey_dsconv_last_variant(void);
 int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y, int y_cstride,
                 ey_stream_t stream);
 
+/* ---- K4+K5 fused: the half-resolution branch of _WaveletEnhancer (block.py:3688-3706) in one kernel (f16 only):
+ *   Z = W_z . cat[ SiLU(f_ll(LL)+b), SiLU(f_h(LH)+b), SiLU(f_h(HL)+b), SiLU(f_h(HH)+b) ]   with (LL,LH,HL,HH) = Haar DWT of x
+ * x [B,H,W,C] -> z [B,H/2,W/2,C].  w_sub_packed: two ey_conv_pack_weight(EY_F16, C/2, C, 3) sets w_set_stride ELEMENTS apart (set 0 =
+ * f_ll written as a centre-tap 3x3, set 1 = the shared f_h); b_sub fp32 [2][C/2]; w_z_packed = ey_conv_pack_weight(EY_F16, C, 2C, 1)
+ * (the fuse conv's columns over the processed sub-bands with the band weights folded in).  C in {16,32,64,128}; EY_EUNSUPPORTED
+ * otherwise / for fp32 (run ey_dwt_haar + ey_conv2d x2).  Replaces three launches and the HBM round trip of the 4C-channel sub-band
+ * tensor and the 2C-channel P. */
+int ey_wavelet_z(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, const void* w_sub_packed, long w_set_stride, const float* b_sub,
+                 const void* w_z_packed, void* z, int z_cstride, ey_stream_t stream);
+
 /* ---- K6: the three chained 5x5/s1/p2 max-pools of SPPF (block.py:219-223): y1=mp(x), y2=mp(y1), y3=mp(y2). */
 int ey_sppf_pool(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y1, void* y2, void* y3,
                  int y_cstride, ey_stream_t stream);

@@ -116,6 +116,28 @@ def test_wavelet_enhancer(M, dtype, h, w):
     check(to_dev(m, dtype)(xd), om.wavelet_enhancer(sd, "enh", x), dtype)
 
 
+@pytest.mark.parametrize("c,h,w,b", [(16, 160, 160, 2), (32, 80, 80, 3), (64, 40, 40, 2), (128, 20, 20, 3), (64, 21, 37, 2), (16, 6, 4, 1), (32, 50, 34, 2)])
+def test_wavelet_z_kernel_vs_oracle_and_unfused(M, c, h, w, b):
+    """ey_wavelet_z (f16: Haar DWT + f_ll / f_h sub-band convs + the Z contraction in ONE kernel) at the network's real (c, map) pairs,
+    odd maps and tiles that overhang the map: against the fp32 oracle enhancer (f16 tolerance) and against the three-launch f16 form
+    (same rounding points: tight)."""
+    from edge_yolo_amd.nn.modules.block import _WaveletEnhancer
+    from edge_yolo_amd import profiling
+    m = _WaveletEnhancer(c)
+    sd = load_synth(m, f"enh{c}")
+    x, xd = _x(b, c, h, w, torch.float16)
+    mh = to_dev(m, torch.float16)
+    with profiling.trace() as t:
+        got = mh(xd)
+    assert [r[0] for r in t.records][0] == "wavelet_z_kernel" and len(t.records) == 2, [r[0] for r in t.records]
+    mh.fused_z = False
+    three = mh(xd)
+    torch.cuda.synchronize()
+    scale = float(three.float().abs().max())
+    assert float((got.float() - three.float()).abs().max()) <= 3e-3 * scale
+    check(got, om.wavelet_enhancer(sd, f"enh{c}", x), torch.float16, scale=max(1.0, scale))
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("c1,c2,dsc3k,e", [(32, 64, False, 0.25), (128, 128, True, 0.5), (384, 128, False, 0.5)])
 def test_dsc3k2_wavelet(M, dtype, c1, c2, dsc3k, e):
