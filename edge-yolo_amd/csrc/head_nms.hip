@@ -458,6 +458,20 @@ __device__ __forceinline__ unsigned long long nms_sort1024(unsigned long long ke
   return key;
 }
 
+// "keep candidate j iff it is alive and no KEPT earlier candidate of the wave suppresses it" (mysup: bit i = earlier candidate i overlaps
+// me).  The greedy answer is the unique fixed point of  K[j] = alive[j] & ((mysup[j] & K) == 0)  -- by induction over j any fixed point
+// equals the sequential result -- and iterating from K = alive fixes one more leading position per round at worst, in practice the depth
+// of the suppression chains (a handful): a few wave-wide ballots instead of a 64-step scalar scan.  Terminates when K stops changing.
+__device__ __forceinline__ unsigned long long nms_resolve(unsigned long long mysup, bool alive) {
+  unsigned long long K = __ballot(alive);
+  for (int it = 0; it < 64; ++it) {
+    const unsigned long long Kn = __ballot(alive && (mysup & K) == 0ull);
+    if (Kn == K) break;
+    K = Kn;
+  }
+  return K;
+}
+
 __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
                                                                  float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
@@ -481,6 +495,10 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
   if (tid == 0) { S.nkept = 0; S.processed = 0; S.part = partition; S.rmin = INFINITY; S.rmax = -INFINITY; }
   if (tid < 16) S.npk[tid] = 0;
   unsigned short* pkl = reinterpret_cast<unsigned short*>(kept + max_det);  // [16][max_det]: ranks of the boxes each owner wave has kept so far
+  // result rows are collected in LDS and written once at the end: a global store inside the suppression loop would sit on the critical
+  // path of every round (the next workgroup barrier waits for it to complete)
+  float* orow = reinterpret_cast<float*>(pkl + (partition ? 16 * max_det : 0));  // [max_det][6]
+  int* oidx = reinterpret_cast<int*>(orow + 6 * max_det);                          // [max_det]
   KeptBox* cbox = &S.wbox[0][0];                                             // [1024]: the chunk's candidate boxes (class offset applied)
   bool need_hist = true;
   __syncthreads();
@@ -666,15 +684,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
                 const KeptBox bi = cbox[__builtin_amdgcn_readlane(idx, i)];
                 if (i < lane && iou_gt(bi.x1, bi.y1, bi.x2, bi.y2, bi.area, me.x1, me.y1, me.x2, me.y2, me.area, iou_thres)) mysup |= 1ull << i;
               }
-              const unsigned sup_lo = (unsigned)mysup, sup_hi = (unsigned)(mysup >> 32);
-              const unsigned long long am = __ballot(al);
-              unsigned long long keptm = 0ull;
-              for (unsigned long long mbits = am; mbits; mbits &= mbits - 1) {
-                const int j = __ffsll((unsigned long long)mbits) - 1;
-                const unsigned long long sj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)sup_hi, j) << 32) |
-                                              (unsigned)__builtin_amdgcn_readlane((int)sup_lo, j);
-                if ((sj & keptm) == 0ull) keptm |= 1ull << j;
-              }
+              const unsigned long long keptm = nms_resolve(mysup, al);
               if ((keptm >> lane) & 1ull) {
                 S.order[base + nck + __popcll(keptm & lt)] = (unsigned short)idx;
                 S.keptflag[idx] = 1;
@@ -694,9 +704,9 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
           for (int w = 0; w < 16; ++w) { const int c = S.wtot2[w]; total += c; if (w < wave) before += c; }
           if (k_i && before < max_det) {
             kept[before] = KeptBox{x1, y1, x2, y2, area};
-            float* ob = out_boxes + ((long)b * max_det + before) * 6;
+            float* ob = orow + before * 6;
             ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
-            if (out_index) out_index[(long)b * max_det + before] = a;
+            oidx[before] = a;
             pkl[owner * max_det + atomicAdd(&S.npk[owner], 1)] = (unsigned short)before;
           }
           __syncthreads();
@@ -716,7 +726,6 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
           if (i < lane && iou_gt(bi.x1, bi.y1, bi.x2, bi.y2, bi.area, x1, y1, x2, y2, area, iou_thres)) mysup |= 1ull << i;
         }
       }
-      const unsigned sup_lo = (unsigned)mysup, sup_hi = (unsigned)(mysup >> 32);
       int checked = 0;
       const int nwaves = min(16, (n - sb + 63) >> 6);
       for (int w = 0; w < nwaves; ++w) {
@@ -744,21 +753,14 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
           // Resolve this wave's 64 candidates: "keep j iff no KEPT earlier candidate suppresses it" is a scan over the
           // pairwise bit masks; the masks are pulled lane by lane with v_readlane (wave-uniform index), so the whole
           // dependent chain runs on the scalar unit.
-          const unsigned long long am = __ballot(alive);
-          unsigned long long keptm = 0ull;
-          for (unsigned long long mbits = am; mbits; mbits &= mbits - 1) {
-            const int j = __ffsll((unsigned long long)mbits) - 1;
-            const unsigned long long sj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)sup_hi, j) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)sup_lo, j);
-            if ((sj & keptm) == 0ull) keptm |= 1ull << j;
-          }
+          const unsigned long long keptm = nms_resolve(mysup, alive);
           const int rank = nk + __popcll(keptm & ((1ull << lane) - 1ull));
           const bool keep = ((keptm >> lane) & 1ull) && rank < max_det;
           if (keep) {
             kept[rank] = KeptBox{x1, y1, x2, y2, area};
-            float* ob = out_boxes + ((long)b * max_det + rank) * 6;
+            float* ob = orow + rank * 6;
             ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
-            if (out_index) out_index[(long)b * max_det + rank] = a;
+            oidx[rank] = a;
             if (partition) pkl[(ci & 15) * max_det + atomicAdd(&S.npk[ci & 15], 1)] = (unsigned short)rank;  // (a later chunk may run class-partitioned)
           }
           if (lane == 0) S.nkept = min(max_det, nk + __popcll(keptm));
@@ -770,9 +772,9 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
   __syncthreads();
   const int nk = min(S.nkept, max_det);
   if (tid == 0) out_count[b] = nk;
-  for (int r = nk * 6 + tid; r < max_det * 6; r += 1024) out_boxes[(long)b * max_det * 6 + r] = 0.f;
+  for (int r = tid; r < max_det * 6; r += 1024) out_boxes[(long)b * max_det * 6 + r] = r < nk * 6 ? orow[r] : 0.f;
   if (out_index)
-    for (int r = nk + tid; r < max_det; r += 1024) out_index[(long)b * max_det + r] = -1;
+    for (int r = tid; r < max_det; r += 1024) out_index[(long)b * max_det + r] = r < nk ? oidx[r] : -1;
 }
 
 static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array length per image (padded for the score kernel grid)
@@ -789,7 +791,8 @@ static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi
   const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
   // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
   const int partition = !agnostic && nc > 1 && cap == 1024;
-  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0);
+  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0) +
+                     (size_t)max_det * 7 * sizeof(float) + 16;
   EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
