@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: exchange the result rows of this many steps with one all_gather")
     ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path on a single GPU (world_size 1)")
     ap.add_argument("--roofline-csv", default="", help="also write roofline.table as CSV (for profiles/)")
+    ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer option: set a dispatch tunable (ey_tune_set, csrc/tune.h) before anything is launched; recorded in the JSON line")
     return ap.parse_args(argv)
 
 
@@ -207,6 +209,11 @@ def main():
     dtype = torch.float16 if a.dtype == "f16" else torch.float32
     conf, iou, max_det = 0.25, 0.7, 300
 
+    if a.tune:
+        from edge_yolo_amd import _lib
+        for kv in a.tune:
+            k, v = kv.split("=")
+            _lib.check(_lib.lib().ey_tune_set(k.encode(), int(v)), f"--tune {kv}")
     from edge_yolo_amd.engine.predictor import GraphRunner, PipelinedRunner
     from edge_yolo_amd.utils import ops
     from edge_yolo_amd import dist as eydist
@@ -308,7 +315,7 @@ def main():
             "config": {"workload": f"{a.model} (scale n, nc={a.nc}) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
                                    f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
-                       "global_batch": a.batch * world, "imgsz": a.imgsz, "nc": a.nc, "pipeline": pipe_desc,
+                       "global_batch": a.batch * world, "imgsz": a.imgsz, "nc": a.nc, "pipeline": pipe_desc, **({"tunables": a.tune} if a.tune else {}),
                        "sharding": f"images x{world}" + (f", RCCL all_gather of boxes every {gather.every} steps" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:

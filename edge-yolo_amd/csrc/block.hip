@@ -92,8 +92,10 @@ __device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)
 // the items round-robin, consecutive waves share a pixel tile (its fragments hit in L1).  A = packed weights (row permutation of
 // ey_conv_pack_weight: lane (r, g) ends up with 4*NTI CONSECUTIVE channels of pixel r), B = pixels by range-checked buffer loads
 // (padding taps, pixel tails and channel tails read zeros).
-template <int MT, int NTI>
-__device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b) {
+// TILE >= 0 (block_tile_kernel: one 256-thread workgroup per 16-pixel tile, pointwise chains): only the items of pixel tile TILE, over
+// the workgroup's 4 waves, with deeper load batches (256 VGPRs per wave there).
+template <int MT, int NTI, bool TILED = false>
+__device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b, int tile = -1) {
   // the stage descriptor lives in global memory: every field the loops use is read ONCE into (scalar) registers here
   const int H = sg.H, W = sg.W, Wo = sg.Wo, kk = sg.k, stride = sg.stride, nsrc = sg.nsrc, Cout = sg.Cout, kpad = sg.kpad;
   const int C0 = sg.src_C[0], C1 = sg.src_C[1], cs0 = sg.src_cs[0], cs1 = sg.src_cs[1];
@@ -115,7 +117,9 @@ __device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b) {
   const int nitems = ngroup * mtiles * nblk * nsub;
   const int pad = kk >> 1;
   const unsigned bytes0 = (unsigned)((((long)H * W - 1) * cs0 + C0) * 2), bytes1 = (unsigned)((((long)H * W - 1) * cs1 + C1) * 2);
-  for (int it = wave; it < nitems; it += BLK_WAVES) {
+  const int per_tile = nblk * nsub;
+  const int it_lo = TILED ? tile * per_tile : 0, it_hi = TILED ? it_lo + per_tile : nitems, nwaves = TILED ? 4 : BLK_WAVES;
+  for (int it = it_lo + wave; it < it_hi; it += nwaves) {
     const int sub = it % nsub;
     int t = it / nsub;
     const int nb = t % nblk;
@@ -147,7 +151,7 @@ __device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b) {
       for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = (f32x4)0.f;
     // ---- K loop: k-steps = (ky, kx, source, 32-channel step), walked U at a time: the loads of U steps are issued back to back
     // (a lone step is one dependent round trip to L2, ~1 us: the loop would be pure latency), then their MFMAs
-    constexpr int U = (MT + NTI <= 3) ? 4 : (MT + NTI <= 5) ? 3 : 2;
+    constexpr int U = TILED ? 4 : (MT + NTI <= 3) ? 4 : (MT + NTI <= 5) ? 3 : 2;
     int ky = 0, kx = 0, si = 0, c0 = 0, kofs = 0;
     bool more = true;
     while (more) {
@@ -372,6 +376,27 @@ __global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- pointwise chains
+// A chain of 1x1 convs (every stage: k = 1, stride 1, one group, the same map) has no coupling between pixels, so it needs no
+// per-image workgroup: one 256-thread workgroup per 16-pixel tile walks the stages, its 4 waves split the output-channel blocks of
+// each stage, a workgroup barrier between stages makes the tile's own intermediate (written to global, L2/L1 resident) visible.
+// All 256 CUs work, every stage is one round trip deep (8 k-steps of loads in flight per wave), and the chain is ONE launch:
+// C2PSA's proj -> ffn -> ffn -> cv2 tail, cv1 -> qkv, the enhancer tail -> cv1|cv2 of DSC3k, DSC3k.cv3 -> DSC3K2.cv2.
+__global__ __launch_bounds__(256) void block_tile_kernel(const BlkStage* __restrict__ prog, int nstages, BlkExt ext) {
+  const int b = blockIdx.y, tile = blockIdx.x;
+  for (int si = 0; si < nstages; ++si) {
+    const BlkStage& s = prog[si];
+    switch (s.tile_nti) {
+      case 1: blk_conv<1, 1, true>(s, ext, b, tile); break;
+      case 2: blk_conv<1, 2, true>(s, ext, b, tile); break;
+      case 4: blk_conv<1, 4, true>(s, ext, b, tile); break;
+      case 5: blk_conv<1, 5, true>(s, ext, b, tile); break;
+      default: break;
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- host side
 static const int kMT[3] = {1, 2, 4};
 
@@ -421,6 +446,15 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
         s.zsx = s.has_addz ? (float)s.addz_W / (float)s.Wo : 0.f;
         if (s.w_gmax < 0) s.w_gmax = 0;
         s.lds = 0;
+        {  // pointwise-chain form (block_tile_kernel): the 4 waves of a tile's workgroup split nblk * NT / nti items; widest nti with >= 4 items
+          const int NT = s.nt_pack, nblk = (s.Cout + 16 * NT - 1) / (16 * NT);
+          s.tile_nti = 0;
+          if (s.k == 1 && s.stride == 1 && s.ngroup == 1) {
+            const int cand[4] = {5, 4, 2, 1};
+            for (int q = 0; q < 4 && !s.tile_nti; ++q)
+              if (NT % cand[q] == 0 && (cand[q] != 5 || NT == 5) && (nblk * (NT / cand[q]) >= 4 || cand[q] == 1)) s.tile_nti = cand[q];
+          }
+        }
         // wave tile (MT pixel tiles x NTI row blocks): operands come fragment-wise through the CU's 64 B/clk vector-memory path, so a
         // round of the 16 waves costs ~(MT + NTI) fragment loads per k-step (the MFMAs hide behind them): fewest rounds x loads wins
         const int M = s.Ho * s.Wo, NT = s.nt_pack, nblk = (s.Cout + 16 * NT - 1) / (16 * NT);
@@ -484,6 +518,30 @@ static int block_launch(const void* program_dev, int nstages, int B, const void*
 
 extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
   return block_launch(program_dev, nstages, B, ext_ptrs_host, next, nullptr, stream);
+}
+
+// Pointwise-chain form: every stage must be tile-executable (ey_block_tileable on the compiled program) and share the map H x W.
+extern "C" int ey_block_tileable(const ey_block_stage* compiled_host, int nstages) {
+  if (!compiled_host || nstages <= 0) return 0;
+  for (int i = 0; i < nstages; ++i) {
+    const ey_block_stage& s = compiled_host[i];
+    if (s.op != EY_BLK_CONV || s.tile_nti == 0 || s.Ho != compiled_host[0].Ho || s.Wo != compiled_host[0].Wo || s.H != s.Ho || s.W != s.Wo) return 0;
+  }
+  return 1;
+}
+extern "C" int ey_block_run_tiles(const void* program_dev, int nstages, int B, int H, int W, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
+  EY_CHECK(program_dev && nstages > 0 && B > 0 && H > 0 && W > 0, "block_run_tiles: null / empty program");
+  EY_CHECK(next >= 0 && next <= BLK_MAX_EXT && (next == 0 || ext_ptrs_host), "block_run_tiles: %d external tensors (0..%d)", next, BLK_MAX_EXT);
+  BlkExt ext;
+  for (int i = 0; i < BLK_MAX_EXT; ++i) {
+    ext.p[i] = i < next ? (char*)const_cast<void*>(ext_ptrs_host[i]) : nullptr;
+    EY_CHECK(i >= next || (ext.p[i] && ey_aligned(ext.p[i], 16)), "block_run_tiles: external tensor %d null / not 16-byte aligned", i);
+  }
+  const int mtiles = (H * W + 15) / 16;
+  EY_CHECK(B <= 65535, "block_run_tiles: batch %d", B);
+  hipLaunchKernelGGL(block_tile_kernel, dim3((unsigned)mtiles, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext);
+  EY_LAUNCH_CHECK("ey_block_run_tiles");
+  return EY_OK;
 }
 // developer tool: same launch; workgroup 0 also writes wall_clock64() (100 MHz) at the start and after every stage into tstamps_dev[nstages + 1]
 extern "C" int ey_block_run_timed(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, long long* tstamps_dev, ey_stream_t stream) {

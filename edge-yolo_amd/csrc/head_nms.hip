@@ -603,8 +603,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
       bool alive = i < n;
       float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, area = 0.f, conf = 0.f, ux1 = 0.f, uy1 = 0.f, ux2 = 0.f, uy2 = 0.f;
       int a = 0, ci = 0;
-      if (alive) {
-        const unsigned long long key = S.chunk[i];
+      auto load_cand = [&](unsigned long long key) {
         a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         conf = __uint_as_float((unsigned)(key >> 32));
         if (multi_label) { ci = a % nc; a = a / nc; }
@@ -615,7 +614,8 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
         const float off = agnostic ? 0.f : __fmul_rn((float)ci, max_wh);  // ops.py:289
         x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
         area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
-      }
+      };
+      if (alive) load_cand(S.chunk[i]);
       if (partition && n <= 1024 && S.part) {
         // ---- class-partitioned greedy.  Valid while all candidates seen so far span less than max_wh in x: boxes of different
         // classes (offset by c * max_wh, ops.py:289) then cannot overlap, exactly as in the reference.
@@ -714,6 +714,41 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
           continue;
         }
       }
+      int checked = 0, nloc = min(1024, n - sb);
+      const int nk0 = S.nkept;  // (uniform: the workgroup passed a barrier since the last write)
+      if (n <= 1024 && nk0 >= 48 && nloc > 128) {
+        // A later chunk: most candidates are already suppressed by boxes kept from earlier chunks (dense scenes keep ~1 in 4).  Test
+        // everybody against those boxes once, in parallel, and COMPACT the survivors (order kept), so that the sequential rounds
+        // below run over 64 live candidates each instead of 64 mostly dead ones.
+        bool sup = false;
+        if (alive) {
+          int k = 0;
+          for (; k + 4 <= nk0; k += 4) {
+            const KeptBox k0 = kept[k], k1 = kept[k + 1], k2 = kept[k + 2], k3 = kept[k + 3];
+            sup |= iou_gt(k0.x1, k0.y1, k0.x2, k0.y2, k0.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k1.x1, k1.y1, k1.x2, k1.y2, k1.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k2.x1, k2.y1, k2.x2, k2.y2, k2.area, x1, y1, x2, y2, area, iou_thres);
+            sup |= iou_gt(k3.x1, k3.y1, k3.x2, k3.y2, k3.area, x1, y1, x2, y2, area, iou_thres);
+          }
+          for (; k < nk0; ++k) {
+            const KeptBox kb = kept[k];
+            sup |= iou_gt(kb.x1, kb.y1, kb.x2, kb.y2, kb.area, x1, y1, x2, y2, area, iou_thres);
+          }
+        }
+        alive = alive && !sup;
+        const unsigned long long am = __ballot(alive);
+        if (lane == 0) S.wtot2[wave] = __popcll(am);
+        __syncthreads();
+        int before = __popcll(am & ((1ull << lane) - 1ull)), total = 0;
+        for (int w = 0; w < 16; ++w) { const int c = S.wtot2[w]; total += c; if (w < wave) before += c; }
+        unsigned long long* comp = S.chunk + 1024;  // (free in this mode: the chunk holds <= 1024 keys)
+        if (alive) comp[before] = S.chunk[i];
+        __syncthreads();
+        nloc = total;
+        alive = tid < nloc;
+        if (alive) load_cand(comp[tid]);
+        checked = nk0;
+      }
       // pairwise pass, all 16 waves at once: bit i of mysup = "earlier candidate i of my wave overlaps me beyond the
       // threshold" (independent of who survives; survival is applied in the scan below)
       S.wbox[wave][lane] = KeptBox{x1, y1, x2, y2, area};
@@ -726,8 +761,7 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
           if (i < lane && iou_gt(bi.x1, bi.y1, bi.x2, bi.y2, bi.area, x1, y1, x2, y2, area, iou_thres)) mysup |= 1ull << i;
         }
       }
-      int checked = 0;
-      const int nwaves = min(16, (n - sb + 63) >> 6);
+      const int nwaves = min(16, (nloc + 63) >> 6);
       for (int w = 0; w < nwaves; ++w) {
         __syncthreads();
         const int nk = S.nkept;

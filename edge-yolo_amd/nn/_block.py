@@ -148,7 +148,9 @@ class BlockRecorder:
         self._push(st)
 
     # -- finish: external tensors -> (index, byte offset); compile; upload
-    def finish(self, ins, outs, tag=""):
+    def finish(self, ins, outs, tag="", tiled=False):
+        """tiled=True: the chain must be pointwise (1x1 convs on one map): it then runs as one workgroup per 16-pixel tile over the whole
+        chip (ey_block_run_tiles) instead of one workgroup per image."""
         if not self.stages:
             raise BlockUnsupported("empty chain")
         ext = []  # (storage ptr, nbytes, "in" | "out")
@@ -187,9 +189,11 @@ class BlockRecorder:
         except L.HipLibraryError as e:
             raise BlockUnsupported(str(e)) from e
         dev = ins[0].device
+        cs = (L.BlockStage * n).from_buffer_copy(host.numpy().tobytes())
+        if tiled and not L.lib().ey_block_tileable(cs, n):
+            raise BlockUnsupported("not a pointwise chain")
         prog = BlockProgram(host.to(dev), n, ins, outs, ext, [t for t in self.keep if t is not None], self.flops, self.wbytes, tag)
-        tiles = torch.frombuffer(bytearray(host.numpy().tobytes()), dtype=torch.uint8)
-        cs = (L.BlockStage * n).from_buffer_copy(tiles.numpy().tobytes())
+        prog.tiled, prog.HW = bool(tiled), (cs[0].Ho, cs[0].Wo)
         prog.desc = [f"{d}  tile {cs[i].mt}x{cs[i].nti}{' lds' if cs[i].lds else ''}" if cs[i].op == L.BLK_CONV else d for i, d in enumerate(self.desc)]
         return prog
 
@@ -212,6 +216,7 @@ class BlockProgram:
         self.alg_bytes = sum(t.numel() * t.element_size() for t in list(ins) + list(outs)) + wbytes
         self.first_outs = list(outs)  # the tensors allocated while recording serve the first run
         self.timing = None
+        self.tiled, self.HW = False, (0, 0)
 
     def matches(self, ins):
         return len(ins) == len(self.in_sig) and all(_sig(t) == s for t, s in zip(ins, self.in_sig))
@@ -244,6 +249,10 @@ class BlockProgram:
         if self.timing is not None:  # developer tool (tools/block_stage_times.py): per-stage timestamps of workgroup 0
             L.check(L.lib().ey_block_run_timed(self.prog.data_ptr(), self.n, self.B, arr, len(ptrs), self.timing.data_ptr(), L.stream()), "ey_block_run_timed")
             return outs
+        if self.tiled:
+            with _ops._tr(f"block_tile_kernel<{self.tag}>", self.alg_bytes, self.flops, note=f"{self.n} stages"):
+                L.check(L.lib().ey_block_run_tiles(self.prog.data_ptr(), self.n, self.B, self.HW[0], self.HW[1], arr, len(ptrs), L.stream()), "ey_block_run_tiles")
+            return outs
         with _ops._tr(f"block_kernel<{self.tag}>", self.alg_bytes, self.flops, note=f"{self.n} stages"):
             L.check(L.lib().ey_block_run(self.prog.data_ptr(), self.n, self.B, arr, len(ptrs), L.stream()), "ey_block_run")
         return outs
@@ -252,8 +261,8 @@ class BlockProgram:
 class BlockCache:
     """Programs of one chain keyed by the input signature; `None` marks a signature the block kernel does not take."""
 
-    def __init__(self, tag):
-        self.tag, self.progs = tag, []
+    def __init__(self, tag, tiled=False):
+        self.tag, self.progs, self.tiled = tag, [], tiled
         self.unsupported = set()
 
     def clear(self):
@@ -279,7 +288,7 @@ class BlockCache:
                 got = fn(*ins)
             finally:
                 _ops.RECORD = None
-            prog = rec.finish(ins, got, self.tag)
+            prog = rec.finish(ins, got, self.tag, tiled=self.tiled)
         except BlockUnsupported:
             self.unsupported.add(key)
             return None

@@ -21,6 +21,33 @@ def _slot(buf, i, c):
     return buf[:, i * c:(i + 1) * c]
 
 
+class _Chains(nn.Module):
+    """Mixin: pointwise chains of a block -- runs of 1x1 convs whose pixels do not interact -- as ONE launch each (nn/_block.py tiled
+    programs: recorded from the ordinary module code below, one 256-thread workgroup per 16-pixel tile walks the stages).  The caches
+    hold packed weights, so they are dropped whenever parameters move or reload.  `pw_chains = False` keeps one launch per conv."""
+
+    pw_chains = False  # opt-in: measured on MI355X at batch 32 the tiled chains (54 + 66 us) lose to one launch per conv (36 + 55 us)
+
+    def _chain(self, name):
+        from .._block import BlockCache
+        d = self.__dict__.setdefault("_chain_caches", {})
+        c = d.get(name)
+        if c is None:
+            c = d[name] = BlockCache(f"{type(self).__name__}.{name}", tiled=True)
+        return c
+
+    def _chains_on(self, x):
+        return self.pw_chains and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16 and ops.RECORD is None
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_chain_caches"] = {}
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self.__dict__["_chain_caches"] = {}
+        return super()._load_from_state_dict(*a, **k)
+
+
 class DFL(nn.Module):
     """Integral of the distribution-focal-loss bins (reference block.py:72-90).  Parameter holder: the expectation is
     computed inside the fused head-decode kernel with the fixed weights 0..c1-1."""
@@ -237,8 +264,8 @@ class PSABlock_LinearAttention(nn.Module):
         return self.ffn[1](self.ffn[0](x), out=out, res=x)
 
 
-class C2PSA_LinearAttention(nn.Module):
-    """reference block.py:3452-3497."""
+class C2PSA_LinearAttention(_Chains):
+    """reference block.py:3452-3497.  f16: 7 launches -> 3: [cv1 -> qkv] | linear attention | [proj(+x) -> ffn -> ffn(+x) -> cv2]."""
 
     def __init__(self, c1, c2, n=1, e=0.5, attn_ratio=0.5, num_heads=None, mlp_ratio=2.0, fmap="elu"):
         super().__init__()
@@ -252,11 +279,41 @@ class C2PSA_LinearAttention(nn.Module):
         self.cv2 = Conv(2 * self.c, c1, k=1, s=1)
 
     def forward(self, x, out=None):
+        if len(self.m) == 1 and self._chains_on(x):
+            y = self._forward_chained(x, out)
+            if y is not None:
+                return y
         t = self.cv1(x)
         b = t[:, self.c:]
         for i, m in enumerate(self.m):
             b = m(b, out=t[:, self.c:] if i == len(self.m) - 1 else None)
         return self.cv2(t, out=out)
+
+    def _forward_chained(self, x, out):
+        blk, c = self.m[0], self.c
+        at = blk.attn
+        qkv_w = lambda: fold_bn(at.qkv.weight, at.qkv.bias, None)  # noqa: E731
+        proj_w = lambda: (at.proj.weight.detach().float(), at.proj.bias.detach().float() if at.proj.bias is not None else None)  # noqa: E731
+
+        def head(x0):  # cv1 -> qkv of the attention branch
+            t = self.cv1(x0)
+            return [t, ops.conv2d(at, [t[:, c:]], qkv_w, 1, 1, 0, L.ACT_NONE, tag="qkv")]
+
+        def tail(y, t):  # x1 = b + proj(y); x2 = x1 + ffn(x1) (written over b, in place per pixel); cv2([a | x2])
+            b = t[:, c:]
+            x1 = ops.conv2d(at, [y], proj_w, 1, 1, 0, L.ACT_NONE, res=b, tag="proj")
+            blk.ffn[1](blk.ffn[0](x1), out=b, res=x1)
+            return [self.cv2(t, out=out)]
+
+        got = self._chain("cv1_qkv").run(head, [L.as_nhwc(x)])
+        if got is None:
+            return None
+        t, qkv = got
+        y = ops.linear_attention(qkv, at.num_heads)
+        res = self._chain("proj_ffn_cv2").run(tail, [y, t], [out] if out is not None else None)
+        if res is None:  # (not block-executable: the same tail, one launch per conv)
+            return tail(y, t)[0]
+        return res[0]
 
 
 # ----------------------------------------------------------------------------------------------- DS / wavelet

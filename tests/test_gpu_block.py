@@ -158,3 +158,41 @@ def test_block_stage_ops_vs_standalone_kernels(H, W, B):
             scale = float(w.float().abs().max()) + 1e-6
             assert float((g.float() - w.float()).abs().max()) <= 4e-3 * scale, tag
             assert torch.equal(g, g2), tag
+
+
+def test_c2psa_pointwise_chains_at_real_shape(cfg_dir):
+    """C2PSA_LinearAttention at its real shape (256 channels, 20x20): [cv1 -> qkv] and [proj -> ffn -> ffn -> cv2] as ONE launch each
+    (tiled block programs: one workgroup per 16-pixel tile): 3 launches instead of 7, same result as one launch per conv (same f16
+    rounding points) and the oracle within the f16 tolerance."""
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd import profiling
+    from edge_yolo_amd.nn import modules as M
+    from gpu_util import load_synth, to_dev, check
+    m = M.C2PSA_LinearAttention(256, 256, 1)
+    sd = load_synth(m, "c2psa")
+    x = (synth.synth_images(4, 20, 20, c=256) - 0.5)
+    mh = to_dev(m, torch.float16)
+    mh.pw_chains = True
+    xd = x.cuda().half().contiguous(memory_format=torch.channels_last)
+    with profiling.trace() as t:
+        got = mh(xd)
+    names = [r[0] for r in t.records]
+    assert len(names) == 3 and names[0].startswith("block_tile_kernel") and names[2].startswith("block_tile_kernel"), names
+    again = mh(xd)  # replay of the recorded programs
+    mh.pw_chains = False
+    with profiling.trace() as t2:
+        plain = mh(xd)
+    torch.cuda.synchronize()
+    assert len(t2.records) == 7
+    assert torch.equal(got, again)
+    scale = float(plain.float().abs().max())
+    assert float((got.float() - plain.float()).abs().max()) <= 3e-3 * scale
+    check(got, om.c2psa(sd, "c2psa", x, 1, True), torch.float16, scale=max(1.0, scale))
+    # weights reloaded -> the recorded programs (they hold packed weights) are dropped and re-recorded
+    mh.pw_chains = True
+    sd2 = {k: synth.synth_tensor("other." + k, tuple(v.shape)) for k, v in m.state_dict().items()}
+    mh.load_state_dict({k: v.half() if v.is_floating_point() else v for k, v in sd2.items()})
+    got2 = mh(xd)
+    mh.pw_chains = False
+    plain2 = mh(xd)
+    assert float((got2.float() - plain2.float()).abs().max()) <= 3e-3 * float(plain2.float().abs().max()) and not torch.equal(got2, got)
