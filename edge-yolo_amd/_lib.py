@@ -51,7 +51,7 @@ class BlockStage(C.Structure):
         ("has_addz", C.c_int32), ("addz", C.c_int64), ("addz_ext", C.c_int32), ("addz_img", C.c_int64), ("addz_cs", C.c_int32), ("addz_H", C.c_int32),
         ("addz_W", C.c_int32), ("out_scale", C.c_float),
         ("ngroup", C.c_int32), ("src_g", C.c_int64), ("y_g", C.c_int64), ("heads", C.c_int32),
-        ("kpad", C.c_int32), ("nt_pack", C.c_int32), ("mt", C.c_int32), ("nti", C.c_int32), ("lds", C.c_int32), ("tile_nti", C.c_int32), ("zsy", C.c_float), ("zsx", C.c_float),
+        ("kpad", C.c_int32), ("nt_pack", C.c_int32), ("mt", C.c_int32), ("nti", C.c_int32), ("lds", C.c_int32), ("tile_nti", C.c_int32), ("tile_src_lds", C.c_int32 * 2), ("tile_src_lcs", C.c_int32 * 2), ("tile_y_lds", C.c_int32), ("tile_y_lcs", C.c_int32), ("tile_res_lds", C.c_int32), ("tile_res_lcs", C.c_int32), ("tile_lds_bytes", C.c_int32), ("zsy", C.c_float), ("zsx", C.c_float),
     ]
 
 
@@ -97,7 +97,7 @@ SIGNATURES = {
     "ey_block_compile": (_i, [C.POINTER(BlockStage), _i, _vp, _sz]),
     "ey_block_run": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p), _i, _vp]),
     "ey_block_tileable": (_i, [C.POINTER(BlockStage), _i]),
-    "ey_block_run_tiles": (_i, [_vp, _i, _i, _i, _i, C.POINTER(C.c_void_p), _i, _vp]),
+    "ey_block_run_tiles": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(C.c_void_p), _i, _vp]),
     "ey_block_run_timed": (_i, [_vp, _i, _i, C.POINTER(C.c_void_p), _i, _vp, _vp]),
     "ey_nms_candidates_bytes": (_sz, [_i, _i]),
     "ey_head_decode_levels_nms": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _f, _vp, _vp, _sz, _vp]),

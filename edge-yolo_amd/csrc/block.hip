@@ -46,7 +46,8 @@ struct BlkEpi {
   float zsy, zsx, out_scale;
 };
 template <int NTI>
-__device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)[NTI], int m, int oy, int ox) {
+__device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)[NTI], int m, int oy, int ox, int yrow = -1, int rrow = -1) {
+  // (yrow / rrow: row index inside an LDS-resident tile instead of the pixel index m, block_tile_kernel)
   long z00 = 0, z01 = 0, z10 = 0, z11 = 0;
   float ly0 = 0.f, ly1 = 0.f, lx0 = 0.f, lx1 = 0.f;
   if (e.z) {  // F.interpolate(size=(Ho,Wo), bilinear, align_corners=False): ATen area_pixel_compute_source_index, scale = in/out
@@ -57,8 +58,8 @@ __device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)
     z00 = (long)(y0 * e.Wz + x0) * e.addz_cs; z01 = (long)(y0 * e.Wz + x1) * e.addz_cs;
     z10 = (long)(y1 * e.Wz + x0) * e.addz_cs; z11 = (long)(y1 * e.Wz + x1) * e.addz_cs;
   }
-  f16* yp = e.y + (long)m * e.y_cs;
-  const f16* rp = e.res ? e.res + (long)m * e.res_cs : nullptr;
+  f16* yp = e.y + (long)(yrow >= 0 ? yrow : m) * e.y_cs;
+  const f16* rp = e.res ? e.res + (long)(rrow >= 0 ? rrow : m) * e.res_cs : nullptr;
 #pragma unroll
   for (int q = 0; q < NTI; ++q) {
     float v[4];
@@ -92,10 +93,8 @@ __device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)
 // the items round-robin, consecutive waves share a pixel tile (its fragments hit in L1).  A = packed weights (row permutation of
 // ey_conv_pack_weight: lane (r, g) ends up with 4*NTI CONSECUTIVE channels of pixel r), B = pixels by range-checked buffer loads
 // (padding taps, pixel tails and channel tails read zeros).
-// TILE >= 0 (block_tile_kernel: one 256-thread workgroup per 16-pixel tile, pointwise chains): only the items of pixel tile TILE, over
-// the workgroup's 4 waves, with deeper load batches (256 VGPRs per wave there).
-template <int MT, int NTI, bool TILED = false>
-__device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b, int tile = -1) {
+template <int MT, int NTI>
+__device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b) {
   // the stage descriptor lives in global memory: every field the loops use is read ONCE into (scalar) registers here
   const int H = sg.H, W = sg.W, Wo = sg.Wo, kk = sg.k, stride = sg.stride, nsrc = sg.nsrc, Cout = sg.Cout, kpad = sg.kpad;
   const int C0 = sg.src_C[0], C1 = sg.src_C[1], cs0 = sg.src_cs[0], cs1 = sg.src_cs[1];
@@ -117,9 +116,7 @@ __device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b, int tile 
   const int nitems = ngroup * mtiles * nblk * nsub;
   const int pad = kk >> 1;
   const unsigned bytes0 = (unsigned)((((long)H * W - 1) * cs0 + C0) * 2), bytes1 = (unsigned)((((long)H * W - 1) * cs1 + C1) * 2);
-  const int per_tile = nblk * nsub;
-  const int it_lo = TILED ? tile * per_tile : 0, it_hi = TILED ? it_lo + per_tile : nitems, nwaves = TILED ? 4 : BLK_WAVES;
-  for (int it = it_lo + wave; it < it_hi; it += nwaves) {
+  for (int it = wave; it < nitems; it += BLK_WAVES) {
     const int sub = it % nsub;
     int t = it / nsub;
     const int nb = t % nblk;
@@ -151,7 +148,7 @@ __device__ void blk_conv(const BlkStage& sg, const BlkExt& ext, int b, int tile 
       for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = (f32x4)0.f;
     // ---- K loop: k-steps = (ky, kx, source, 32-channel step), walked U at a time: the loads of U steps are issued back to back
     // (a lone step is one dependent round trip to L2, ~1 us: the loop would be pure latency), then their MFMAs
-    constexpr int U = TILED ? 4 : (MT + NTI <= 3) ? 4 : (MT + NTI <= 5) ? 3 : 2;
+    constexpr int U = (MT + NTI <= 3) ? 4 : (MT + NTI <= 5) ? 3 : 2;
     int ky = 0, kx = 0, si = 0, c0 = 0, kofs = 0;
     bool more = true;
     while (more) {
@@ -378,22 +375,135 @@ __global__ __launch_bounds__(BLK_THREADS) void block_kernel(const BlkStage* __re
 
 // ---------------------------------------------------------------------------------------------------------------- pointwise chains
 // A chain of 1x1 convs (every stage: k = 1, stride 1, one group, the same map) has no coupling between pixels, so it needs no
-// per-image workgroup: one 256-thread workgroup per 16-pixel tile walks the stages, its 4 waves split the output-channel blocks of
-// each stage, a workgroup barrier between stages makes the tile's own intermediate (written to global, L2/L1 resident) visible.
-// All 256 CUs work, every stage is one round trip deep (8 k-steps of loads in flight per wave), and the chain is ONE launch:
-// C2PSA's proj -> ffn -> ffn -> cv2 tail, cv1 -> qkv, the enhancer tail -> cv1|cv2 of DSC3k, DSC3k.cv3 -> DSC3K2.cv2.
+// per-image workgroup: one 256-thread workgroup per TILE_PX = 32 pixels walks the stages; its 4 waves split the output-channel blocks
+// of a stage (2 pixel tiles x NTI row blocks per item: every weight fragment feeds two MFMAs).  Built for a short dependent chain per
+// stage: the stage descriptors are resolved ONCE into LDS, intermediates that only the chain reads live in LDS (rows of C + 8
+// halves: conflict-free 16-byte reads), the weight fragments of a whole item are requested in batches of 8 k-steps, and only the
+// chain's outputs go to global memory.  C2PSA's proj -> ffn -> ffn -> cv2 tail, cv1 -> qkv, the enhancer tail -> DSC3k.cv1|cv2,
+// DSC3k.cv3 -> DSC3K2.cv2 (block.py:3412-3497,1506-1562,3749-3788).
+#define TILE_PX 32
+#define TILE_MAX_STAGES 8
+struct TStage {
+  const f16* src[2]; const f16* w; const float* bias; f16* y; const f16* res; const f16* z;
+  int src_lds[2], src_cs[2], src_C[2], nsrc;     // src_lds >= 0: element offset of the source's pixel row 0 in LDS (row stride src_cs)
+  int y_lds, y_cs, res_lds, res_cs;               // same for the output / residual (y_lds >= 0: the stage writes LDS only)
+  int kpad, nt_pack, nti, Cout, act, addz_cs, Hz, Wz;
+  float zsy, zsx, out_scale;
+};
+
+template <int NTI>
+__device__ __forceinline__ void tile_conv(const TStage& t, f16* lds, int b, int m0, int M, int Wo) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int NT = t.nt_pack, BN = 16 * NT, nsub = NT / NTI, nblk = (t.Cout + BN - 1) / BN, nitems = nblk * nsub;
+  const int C0 = t.src_C[0], C1 = t.nsrc > 1 ? t.src_C[1] : 0;
+  const int nks0 = (C0 + 31) >> 5, nks = nks0 + ((C1 + 31) >> 5);
+  const __amdgpu_buffer_rsrc_t rw = ey_rsrc(t.w, (unsigned)((long)nblk * BN * t.kpad * 2));
+  const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(t.src[0], t.src_lds[0] >= 0 ? 0u : (unsigned)((((long)M - 1) * t.src_cs[0] + C0) * 2));
+  const __amdgpu_buffer_rsrc_t rs1 = ey_rsrc(t.nsrc > 1 ? t.src[1] : t.src[0], (t.nsrc < 2 || t.src_lds[1] >= 0) ? 0u : (unsigned)((((long)M - 1) * t.src_cs[1] + C1) * 2));
+  bool pv[2];
+  int mm[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) { mm[mt] = m0 + mt * 16 + r; pv[mt] = mm[mt] < M; }
+  for (int it = wave; it < nitems; it += 4) {
+    const int sub = it % nsub, nb = it / nsub;
+    unsigned woff[NTI];
+#pragma unroll
+    for (int nt = 0; nt < NTI; ++nt) woff[nt] = (unsigned)((((nb * BN + (sub * NTI + nt) * 16 + r) * t.kpad) + 8 * g) * 2);
+    f32x4 acc[2][NTI];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = (f32x4)0.f;
+    constexpr int U = NTI >= 4 ? 4 : 8;  // k-steps per batch of loads (U * NTI weight fragments + 2U pixel fragments in flight)
+    for (int jb = 0; jb < nks; jb += U) {
+      Vec8<f16> af[U][NTI], bf[U][2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = jb + u;
+        const bool on = j < nks, s1 = j >= nks0;                    // (wave-uniform)
+        const int c0 = 32 * (s1 ? j - nks0 : j), Cs = s1 ? C1 : C0;
+        const int kof = s1 ? C0 + c0 : c0;                          // k offset of this step in the packed row
+#pragma unroll
+        for (int nt = 0; nt < NTI; ++nt) BufLoad8<f16>::load(af[u][nt], rw, on ? woff[nt] : EY_OOB, kof * 2);
+        const bool chan_ok = on && c0 + 8 * g < Cs;                 // channel tail of a source that is not a multiple of 32: zeros
+        const int sl = s1 ? t.src_lds[1] : t.src_lds[0], cs = s1 ? t.src_cs[1] : t.src_cs[0];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (sl >= 0) {  // an intermediate of the chain: this tile's rows in LDS
+            if (chan_ok) bf[u][mt].load(lds + sl + (mt * 16 + r) * cs + c0 + 8 * g);
+            else bf[u][mt].zero();
+          } else {
+            const unsigned po = (chan_ok && pv[mt]) ? (unsigned)mm[mt] * (unsigned)(cs * 2) + 16u * g : EY_OOB;
+            if (s1) BufLoad8<f16>::load(bf[u][mt], rs1, po, c0 * 2);
+            else BufLoad8<f16>::load(bf[u][mt], rs0, po, c0 * 2);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (jb + u < nks) {
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTI; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u][nt].v, bf[u][mt].v, acc[mt][nt], 0, 0, 0);
+        }
+    }
+    const int ch0 = nb * BN + g * 4 * NT + 4 * sub * NTI;
+    if (ch0 >= t.Cout) continue;
+    BlkEpi e;
+    e.bias = t.bias ? t.bias + ch0 : nullptr;
+    e.z = t.z ? t.z + ch0 : nullptr;
+    e.addz_cs = t.addz_cs; e.Hz = t.Hz; e.Wz = t.Wz; e.act = t.act; e.zsy = t.zsy; e.zsx = t.zsx; e.out_scale = t.out_scale;
+    e.y_cs = t.y_cs; e.res_cs = t.res_cs;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (!pv[mt]) continue;
+      // LDS-resident tensors are indexed by the pixel's position in the tile, global ones by the pixel
+      const int row = mt * 16 + r;
+      e.y = (t.y_lds >= 0 ? lds + t.y_lds : t.y) + ch0;
+      e.res = t.res ? (t.res_lds >= 0 ? lds + t.res_lds : t.res) + ch0 : nullptr;
+      const int oy = mm[mt] / Wo;
+      blk_epilogue<NTI>(e, acc[mt], mm[mt], oy, mm[mt] - oy * Wo, t.y_lds >= 0 ? row : -1, (t.res && t.res_lds >= 0) ? row : -1);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void block_tile_kernel(const BlkStage* __restrict__ prog, int nstages, BlkExt ext) {
-  const int b = blockIdx.y, tile = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TStage* ts = reinterpret_cast<TStage*>(smem);                                   // [TILE_MAX_STAGES]
+  f16* lds = reinterpret_cast<f16*>(smem + TILE_MAX_STAGES * sizeof(TStage));     // the tile's chain-internal tensors
+  const int b = blockIdx.y, m0 = blockIdx.x * TILE_PX;
+  if ((int)threadIdx.x < nstages) {  // resolve every stage once (pointers of this image, LDS placement): no global round trip per stage later
+    const BlkStage& s = prog[threadIdx.x];
+    TStage t;
+    for (int j = 0; j < 2; ++j) {
+      const int jj = j < s.nsrc ? j : 0;
+      t.src[j] = blk_ptr(ext, s.src[jj], s.src_ext[jj]) + (long)b * s.src_img[jj];
+      t.src_lds[j] = s.tile_src_lds[jj]; t.src_cs[j] = s.tile_src_lds[jj] >= 0 ? s.tile_src_lcs[jj] : s.src_cs[jj]; t.src_C[j] = s.src_C[jj];
+    }
+    t.nsrc = s.nsrc;
+    t.w = reinterpret_cast<const f16*>(s.w); t.bias = reinterpret_cast<const float*>(s.bias);
+    t.y = const_cast<f16*>(blk_ptr(ext, s.y, s.y_ext)) + (long)b * s.y_img;
+    t.y_lds = s.tile_y_lds; t.y_cs = s.tile_y_lds >= 0 ? s.tile_y_lcs : s.y_cs;
+    t.res = s.has_res ? blk_ptr(ext, s.res, s.res_ext) + (long)b * s.res_img : nullptr;
+    t.res_lds = s.has_res ? s.tile_res_lds : -1; t.res_cs = (s.has_res && s.tile_res_lds >= 0) ? s.tile_res_lcs : s.res_cs;
+    t.z = s.has_addz ? blk_ptr(ext, s.addz, s.addz_ext) + (long)b * s.addz_img : nullptr;
+    t.kpad = s.kpad; t.nt_pack = s.nt_pack; t.nti = s.tile_nti; t.Cout = s.Cout; t.act = s.act; t.addz_cs = s.addz_cs; t.Hz = s.addz_H; t.Wz = s.addz_W;
+    t.zsy = s.zsy; t.zsx = s.zsx; t.out_scale = s.out_scale;
+    ts[threadIdx.x] = t;
+  }
+  const int M = prog[0].Ho * prog[0].Wo, Wo = prog[0].Wo;
+  __syncthreads();
   for (int si = 0; si < nstages; ++si) {
-    const BlkStage& s = prog[si];
-    switch (s.tile_nti) {
-      case 1: blk_conv<1, 1, true>(s, ext, b, tile); break;
-      case 2: blk_conv<1, 2, true>(s, ext, b, tile); break;
-      case 4: blk_conv<1, 4, true>(s, ext, b, tile); break;
-      case 5: blk_conv<1, 5, true>(s, ext, b, tile); break;
+    const TStage& t = ts[si];
+    switch (t.nti) {
+      case 1: tile_conv<1>(t, lds, b, m0, M, Wo); break;
+      case 2: tile_conv<2>(t, lds, b, m0, M, Wo); break;
+      case 4: tile_conv<4>(t, lds, b, m0, M, Wo); break;
+      case 5: tile_conv<5>(t, lds, b, m0, M, Wo); break;
       default: break;
     }
-    __syncthreads();
+    __syncthreads();  // the tile's stage output (LDS, or global written by this workgroup) is visible to the next stage
   }
 }
 
@@ -494,6 +604,47 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
     }
     o[i] = s;
   }
+  // ---- pointwise-chain lowering (block_tile_kernel): tensors that only the chain touches (absolute refs produced by a stage) live in
+  // LDS, one row of C + 8 halves per pixel of the 32-pixel tile; everything else stays in global memory
+  {
+    struct Own { int64_t addr; int cs, C, lds, lcs; };
+    Own own[TILE_MAX_STAGES];
+    int nown = 0;
+    long top = 0;
+    bool ok = nstages <= TILE_MAX_STAGES;
+    for (int i = 0; i < nstages && ok; ++i) {
+      ey_block_stage& s = o[i];
+      if (s.op != EY_BLK_CONV || s.tile_nti == 0) { ok = false; break; }
+      auto find = [&](int64_t addr, int ext, int cs, int& lds, int& lcs) {
+        lds = -1; lcs = 0;
+        if (ext >= 0) return;
+        for (int q = 0; q < nown; ++q)
+          if (own[q].cs == cs && addr >= own[q].addr && addr < own[q].addr + (int64_t)own[q].C * 2) {
+            lds = own[q].lds + (int)((addr - own[q].addr) / 2);
+            lcs = own[q].lcs;
+          }
+      };
+      for (int j = 0; j < 2; ++j) {
+        s.tile_src_lds[j] = -1; s.tile_src_lcs[j] = 0;
+        if (j < s.nsrc) find(s.src[j], s.src_ext[j], s.src_cs[j], s.tile_src_lds[j], s.tile_src_lcs[j]);
+      }
+      s.tile_res_lds = -1; s.tile_res_lcs = 0;
+      if (s.has_res) find(s.res, s.res_ext, s.res_cs, s.tile_res_lds, s.tile_res_lcs);
+      s.tile_y_lds = -1; s.tile_y_lcs = 0;
+      if (s.y_ext < 0) {  // an intermediate the caller never sees
+        int lds, lcs;
+        find(s.y, s.y_ext, s.y_cs, lds, lcs);
+        if (lds >= 0) { s.tile_y_lds = lds; s.tile_y_lcs = lcs; }  // (written into a slice of an earlier intermediate)
+        else {
+          Own w; w.addr = s.y; w.cs = s.y_cs; w.C = s.Cout; w.lcs = s.Cout + 8; w.lds = (int)top;
+          top += (long)TILE_PX * w.lcs;
+          own[nown++] = w;
+          s.tile_y_lds = w.lds; s.tile_y_lcs = w.lcs;
+        }
+      }
+    }
+    o[0].tile_lds_bytes = (ok && top * 2 <= 56 * 1024) ? (int32_t)(top * 2) : -1;
+  }
   return EY_OK;
 }
 
@@ -522,24 +673,27 @@ extern "C" int ey_block_run(const void* program_dev, int nstages, int B, const v
 
 // Pointwise-chain form: every stage must be tile-executable (ey_block_tileable on the compiled program) and share the map H x W.
 extern "C" int ey_block_tileable(const ey_block_stage* compiled_host, int nstages) {
-  if (!compiled_host || nstages <= 0) return 0;
+  if (!compiled_host || nstages <= 0 || nstages > TILE_MAX_STAGES || compiled_host[0].tile_lds_bytes < 0) return 0;
   for (int i = 0; i < nstages; ++i) {
     const ey_block_stage& s = compiled_host[i];
     if (s.op != EY_BLK_CONV || s.tile_nti == 0 || s.Ho != compiled_host[0].Ho || s.Wo != compiled_host[0].Wo || s.H != s.Ho || s.W != s.Wo) return 0;
   }
   return 1;
 }
-extern "C" int ey_block_run_tiles(const void* program_dev, int nstages, int B, int H, int W, const void* const* ext_ptrs_host, int next, ey_stream_t stream) {
-  EY_CHECK(program_dev && nstages > 0 && B > 0 && H > 0 && W > 0, "block_run_tiles: null / empty program");
+extern "C" int ey_block_run_tiles(const void* program_dev, int nstages, int B, int H, int W, int lds_bytes, const void* const* ext_ptrs_host, int next,
+                                  ey_stream_t stream) {
+  EY_CHECK(program_dev && nstages > 0 && nstages <= TILE_MAX_STAGES && B > 0 && H > 0 && W > 0 && lds_bytes >= 0 && lds_bytes <= 56 * 1024,
+           "block_run_tiles: bad program (%d stages, %d B of LDS)", nstages, lds_bytes);
   EY_CHECK(next >= 0 && next <= BLK_MAX_EXT && (next == 0 || ext_ptrs_host), "block_run_tiles: %d external tensors (0..%d)", next, BLK_MAX_EXT);
   BlkExt ext;
   for (int i = 0; i < BLK_MAX_EXT; ++i) {
     ext.p[i] = i < next ? (char*)const_cast<void*>(ext_ptrs_host[i]) : nullptr;
     EY_CHECK(i >= next || (ext.p[i] && ey_aligned(ext.p[i], 16)), "block_run_tiles: external tensor %d null / not 16-byte aligned", i);
   }
-  const int mtiles = (H * W + 15) / 16;
+  const int mtiles = (H * W + TILE_PX - 1) / TILE_PX;
   EY_CHECK(B <= 65535, "block_run_tiles: batch %d", B);
-  hipLaunchKernelGGL(block_tile_kernel, dim3((unsigned)mtiles, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext);
+  const size_t lds = TILE_MAX_STAGES * sizeof(TStage) + (size_t)lds_bytes;
+  hipLaunchKernelGGL(block_tile_kernel, dim3((unsigned)mtiles, (unsigned)B), dim3(256), lds, (hipStream_t)stream, (const BlkStage*)program_dev, nstages, ext);
   EY_LAUNCH_CHECK("ey_block_run_tiles");
   return EY_OK;
 }

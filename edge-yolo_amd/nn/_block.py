@@ -193,7 +193,7 @@ class BlockRecorder:
         if tiled and not L.lib().ey_block_tileable(cs, n):
             raise BlockUnsupported("not a pointwise chain")
         prog = BlockProgram(host.to(dev), n, ins, outs, ext, [t for t in self.keep if t is not None], self.flops, self.wbytes, tag)
-        prog.tiled, prog.HW = bool(tiled), (cs[0].Ho, cs[0].Wo)
+        prog.tiled, prog.HW, prog.tile_lds = bool(tiled), (cs[0].Ho, cs[0].Wo), int(cs[0].tile_lds_bytes)
         prog.desc = [f"{d}  tile {cs[i].mt}x{cs[i].nti}{' lds' if cs[i].lds else ''}" if cs[i].op == L.BLK_CONV else d for i, d in enumerate(self.desc)]
         return prog
 
@@ -216,7 +216,7 @@ class BlockProgram:
         self.alg_bytes = sum(t.numel() * t.element_size() for t in list(ins) + list(outs)) + wbytes
         self.first_outs = list(outs)  # the tensors allocated while recording serve the first run
         self.timing = None
-        self.tiled, self.HW = False, (0, 0)
+        self.tiled, self.HW, self.tile_lds = False, (0, 0), 0
 
     def matches(self, ins):
         return len(ins) == len(self.in_sig) and all(_sig(t) == s for t, s in zip(ins, self.in_sig))
@@ -251,7 +251,7 @@ class BlockProgram:
             return outs
         if self.tiled:
             with _ops._tr(f"block_tile_kernel<{self.tag}>", self.alg_bytes, self.flops, note=f"{self.n} stages"):
-                L.check(L.lib().ey_block_run_tiles(self.prog.data_ptr(), self.n, self.B, self.HW[0], self.HW[1], arr, len(ptrs), L.stream()), "ey_block_run_tiles")
+                L.check(L.lib().ey_block_run_tiles(self.prog.data_ptr(), self.n, self.B, self.HW[0], self.HW[1], self.tile_lds, arr, len(ptrs), L.stream()), "ey_block_run_tiles")
             return outs
         with _ops._tr(f"block_kernel<{self.tag}>", self.alg_bytes, self.flops, note=f"{self.n} stages"):
             L.check(L.lib().ey_block_run(self.prog.data_ptr(), self.n, self.B, arr, len(ptrs), L.stream()), "ey_block_run")

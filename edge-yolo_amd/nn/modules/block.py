@@ -26,7 +26,9 @@ class _Chains(nn.Module):
     programs: recorded from the ordinary module code below, one 256-thread workgroup per 16-pixel tile walks the stages).  The caches
     hold packed weights, so they are dropped whenever parameters move or reload.  `pw_chains = False` keeps one launch per conv."""
 
-    pw_chains = False  # opt-in: measured on MI355X at batch 32 the tiled chains (54 + 66 us) lose to one launch per conv (36 + 55 us)
+    # True, False, or a tuple of chain names.  Measured on MI355X at batch 32 (C2PSA at 256 channels, 20x20): the four-conv tail as one
+    # launch 43 us vs 55 us for four launches; the two-conv head 43 us vs 36 us (its 16 MB of outputs bound it, not launches)
+    pw_chains = ("proj_ffn_cv2",)
 
     def _chain(self, name):
         from .._block import BlockCache
@@ -36,8 +38,9 @@ class _Chains(nn.Module):
             c = d[name] = BlockCache(f"{type(self).__name__}.{name}", tiled=True)
         return c
 
-    def _chains_on(self, x):
-        return self.pw_chains and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16 and ops.RECORD is None
+    def _chains_on(self, x, name=None):
+        on = self.pw_chains if isinstance(self.pw_chains, bool) else (name is None or name in self.pw_chains)
+        return bool(on) and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16 and ops.RECORD is None
 
     def _apply(self, fn, *a, **k):
         self.__dict__["_chain_caches"] = {}
@@ -305,12 +308,10 @@ class C2PSA_LinearAttention(_Chains):
             blk.ffn[1](blk.ffn[0](x1), out=b, res=x1)
             return [self.cv2(t, out=out)]
 
-        got = self._chain("cv1_qkv").run(head, [L.as_nhwc(x)])
-        if got is None:
-            return None
-        t, qkv = got
+        got = self._chain("cv1_qkv").run(head, [L.as_nhwc(x)]) if self._chains_on(x, "cv1_qkv") else None
+        t, qkv = got if got is not None else head(L.as_nhwc(x))
         y = ops.linear_attention(qkv, at.num_heads)
-        res = self._chain("proj_ffn_cv2").run(tail, [y, t], [out] if out is not None else None)
+        res = self._chain("proj_ffn_cv2").run(tail, [y, t], [out] if out is not None else None) if self._chains_on(x, "proj_ffn_cv2") else None
         if res is None:  # (not block-executable: the same tail, one launch per conv)
             return tail(y, t)[0]
         return res[0]

@@ -271,6 +271,7 @@ typedef struct {
   int32_t heads;               /* LINATTN: heads of 64 channels, even */
   /* filled by ey_block_compile */
   int32_t kpad, nt_pack, mt, nti, lds, tile_nti;
+  int32_t tile_src_lds[2], tile_src_lcs[2], tile_y_lds, tile_y_lcs, tile_res_lds, tile_res_lcs, tile_lds_bytes;  /* pointwise-chain LDS placement */
   float zsy, zsx;
 } ey_block_stage;
 size_t ey_block_stage_sizeof(void);
@@ -280,10 +281,11 @@ int ey_block_compile(const ey_block_stage* stages_host, int nstages, void* out_h
 /* One launch: grid = B workgroups.  ext_ptrs_host: the `next` (<= 8) external tensors' device base pointers (host array, read at call time). */
 int ey_block_run(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, ey_stream_t stream);
 /* Pointwise chains: when every stage is a 1x1 / stride-1 / single-group conv on one map (ey_block_tileable(compiled program) != 0) the
- * pixels do not interact, and the program runs as one 256-thread workgroup per 16-pixel tile (grid = tiles x B: the whole chip) instead
- * of one workgroup per image: C2PSA's proj -> ffn -> ffn -> cv2, cv1 -> qkv, DSC3k's cv3 -> cv2 (block.py:3412-3497,1506-1562). */
+ * pixels do not interact, and the program runs as one 256-thread workgroup per 32-pixel tile (grid = tiles x B: the whole chip) instead
+ * of one workgroup per image, chain-internal tensors in LDS: C2PSA's proj -> ffn -> ffn -> cv2, cv1 -> qkv, DSC3k's cv3 -> cv2 (block.py:3412-3497,1506-1562). */
 int ey_block_tileable(const ey_block_stage* compiled_host, int nstages);
-int ey_block_run_tiles(const void* program_dev, int nstages, int B, int H, int W, const void* const* ext_ptrs_host, int next, ey_stream_t stream);
+int ey_block_run_tiles(const void* program_dev, int nstages, int B, int H, int W, int lds_bytes /* compiled stage 0's tile_lds_bytes */,
+                       const void* const* ext_ptrs_host, int next, ey_stream_t stream);
 /* Developer tool: the same launch; workgroup 0 also stores wall_clock64() (100 MHz ticks) at the start and after every stage into
  * tstamps_dev[nstages + 1] (tools/block_stage_times.py prints the per-stage split). */
 int ey_block_run_timed(const void* program_dev, int nstages, int B, const void* const* ext_ptrs_host, int next, long long* tstamps_dev, ey_stream_t stream);
