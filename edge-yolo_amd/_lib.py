@@ -92,6 +92,9 @@ SIGNATURES = {
     "ey_softmax_attention": (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp]),
     "ey_head_decode": (_i, [_i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ey_head_decode_levels": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "ey_head_decode_levels_xyxy": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "ey_e2e_topk_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ey_e2e_topk": (_i, [_i, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "ey_block_stage_sizeof": (_sz, []),
     "ey_block_program_bytes": (_sz, [_i]),
     "ey_block_compile": (_i, [C.POINTER(BlockStage), _i, _vp, _sz]),

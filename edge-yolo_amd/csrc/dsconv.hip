@@ -272,11 +272,7 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
         BufLoad8<T>::load(xr[j], rx, (yok && ix >= 0 && ix < p.W) ? (unsigned)((rowoff + j * p.xCs) * (int)sizeof(T)) : EY_OOB);
       }
     };
-    Vec8<T> xin[NX], xnx[NX];
-    load_row(0, xin);
-#pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-      if (ky + 1 < K) load_row(ky + 1, xnx);
+    auto mac_row = [&](int ky, const Vec8<T> (&xr)[NX]) {
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         Vec8<T> w;
@@ -285,10 +281,26 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
 #pragma unroll
         for (int q = 0; q < P; ++q)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xin[q + kx].get(i), w.get(i), acc[q][i]);
+          for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xr[q + kx].get(i), w.get(i), acc[q][i]);
       }
+    };
+    if constexpr (K * NX <= 16) {
+      // small stencils (3x3 with short strips): ALL K*NX loads in flight at once -- one memory round trip per channel step instead of K
+      Vec8<T> xall[K][NX];
 #pragma unroll
-      for (int j = 0; j < NX; ++j) xin[j] = xnx[j];
+      for (int ky = 0; ky < K; ++ky) load_row(ky, xall[ky]);
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) mac_row(ky, xall[ky]);
+    } else {
+      Vec8<T> xin[NX], xnx[NX];
+      load_row(0, xin);
+#pragma unroll 1
+      for (int ky = 0; ky < K; ++ky) {
+        if (ky + 1 < K) load_row(ky + 1, xnx);
+        mac_row(ky, xin);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xin[j] = xnx[j];
+      }
     }
 #pragma unroll
     for (int q = 0; q < P; ++q)

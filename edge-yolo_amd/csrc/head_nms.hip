@@ -33,6 +33,7 @@ struct HdNms {
   const uint8_t* mask;       // [nc] or null
   float conf;
   int P;
+  int xyxy;  // end2end heads: rows 0-3 of pred = x1,y1,x2,y2 (decode_bboxes with xywh=False, head.py:163-165) instead of cx,cy,w,h
 };
 template <typename T>
 __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv, int nc, int hid, float* __restrict__ pred, int A, int boxLs, int clsLs, int vec, HdNms nm) {
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
   int bi = 0;
   if (pred) {
     float* pp = pred + (long)b * (4 + nc) * A + a_off + a;
-    pp[0] = bcx; pp[(long)A] = bcy; pp[2L * A] = bw; pp[3L * A] = bh;
+    if (nm.xyxy) { pp[0] = x1 * stride; pp[(long)A] = y1 * stride; pp[2L * A] = x2 * stride; pp[3L * A] = y2 * stride; }  // dist2bbox(xywh=False) * strides
+    else { pp[0] = bcx; pp[(long)A] = bcy; pp[2L * A] = bw; pp[3L * A] = bh; }
     if (vec) {
       for (int c8 = 0; c8 < nc; c8 += 8) {
         Vec8<T> t;
@@ -246,7 +248,15 @@ extern "C" int ey_head_decode_levels(int dtype, int B, int nlevels, const int* H
                                      const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
                                      const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, ey_stream_t stream) {
   EY_CHECK(pred, "head_decode: null pred");
-  HdNms nm = {nullptr, nullptr, nullptr, nullptr, 0.f, 0};
+  HdNms nm = {nullptr, nullptr, nullptr, nullptr, 0.f, 0, 0};
+  return head_decode_impl(dtype, B, nlevels, H, W, stride, box, box_cstride, cls, cls_cstride, nc, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, nm, stream);
+}
+
+extern "C" int ey_head_decode_levels_xyxy(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box, const int* box_cstride,
+                                          const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1, const float* const* q_b1,
+                                          const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred, int A_total, const int* a_off, ey_stream_t stream) {
+  EY_CHECK(pred, "head_decode: null pred");
+  HdNms nm = {nullptr, nullptr, nullptr, nullptr, 0.f, 0, 1};
   return head_decode_impl(dtype, B, nlevels, H, W, stride, box, box_cstride, cls, cls_cstride, nc, q_w1, q_b1, q_w2, q_b2, q_hidden, pred, A_total, a_off, nm, stream);
 }
 
@@ -272,6 +282,7 @@ extern "C" int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const in
   nm.mask = class_mask;
   nm.conf = conf_thres;
   nm.P = P;
+  nm.xyxy = 0;
   return head_decode_impl(dtype, B, nlevels, H, W, stride, box, box_cstride, cls, cls_cstride, nc, q_w1, q_b1, q_w2, q_b2, q_hidden, pred_or_null, A_total, a_off, nm, stream);
 }
 
@@ -391,6 +402,8 @@ __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay
 //  candidates actually needed, not A: no full sort.
 #define NMS_CAP 4096
 #define NMS_TARGET 2048
+#define NMS_MODE_XYXY 1  // box rows are x1,y1,x2,y2
+#define NMS_MODE_TOPK 2  // keep the best max_det candidates in score order, no suppression
 
 struct NmsShared {
   unsigned hist[4096];
@@ -473,7 +486,7 @@ __device__ __forceinline__ unsigned long long nms_resolve(unsigned long long mys
 }
 
 __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
-                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition,
+                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition, int mode,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
                                                                  int* __restrict__ out_index) {
@@ -608,14 +621,28 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
         conf = __uint_as_float((unsigned)(key >> 32));
         if (multi_label) { ci = a % nc; a = a / nc; }
         const float cx = pb[a], cy = pb[(long)A + a], w = pb[2L * A + a], h = pb[3L * A + a];
-        const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432 (x/2 is exact)
-        ux1 = __fsub_rn(cx, hw); uy1 = __fsub_rn(cy, hh); ux2 = __fadd_rn(cx, hw); uy2 = __fadd_rn(cy, hh);
+        if (mode & NMS_MODE_XYXY) { ux1 = cx; uy1 = cy; ux2 = w; uy2 = h; }  // rows already hold x1,y1,x2,y2 (end2end heads)
+        else {
+          const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432 (x/2 is exact)
+          ux1 = __fsub_rn(cx, hw); uy1 = __fsub_rn(cy, hh); ux2 = __fadd_rn(cx, hw); uy2 = __fadd_rn(cy, hh);
+        }
         if (!multi_label) ci = cid[a];
         const float off = agnostic ? 0.f : __fmul_rn((float)ci, max_wh);  // ops.py:289
         x1 = __fadd_rn(ux1, off); y1 = __fadd_rn(uy1, off); x2 = __fadd_rn(ux2, off); y2 = __fadd_rn(uy2, off);
         area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
       };
       if (alive) load_cand(S.chunk[i]);
+      if (mode & NMS_MODE_TOPK) {  // no suppression: the sorted candidates ARE the result rows (Detect.postprocess, head.py:167-189)
+        const int nk0 = S.nkept, rank = nk0 + tid;
+        if (alive && rank < max_det) {
+          float* ob = orow + rank * 6;
+          ob[0] = ux1; ob[1] = uy1; ob[2] = ux2; ob[3] = uy2; ob[4] = conf; ob[5] = (float)ci;
+          oidx[rank] = a;
+        }
+        __syncthreads();
+        if (tid == 0) S.nkept = min(max_det, nk0 + min(1024, n - sb));
+        continue;
+      }
       if (partition && n <= 1024 && S.part) {
         // ---- class-partitioned greedy.  Valid while all candidates seen so far span less than max_wh in x: boxes of different
         // classes (offset by c * max_wh, ops.py:289) then cannot overlap, exactly as in the reference.
@@ -821,28 +848,26 @@ extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size
 // A*nc keys with the largest chunk the LDS sort takes.
 static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
                              float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
-                             hipStream_t st) {
+                             hipStream_t st, int mode = 0) {
   const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
   // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
-  const int partition = !agnostic && nc > 1 && cap == 1024;
+  const int partition = !agnostic && nc > 1 && cap == 1024 && !(mode & NMS_MODE_TOPK);
   const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0) +
                      (size_t)max_det * 7 * sizeof(float) + 16;
   EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
   hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
-                     target, cap, partition, keys, cls_id, out_boxes, out_count, out_index);
+                     target, cap, partition, mode, keys, cls_id, out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }
 
-extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
-                      int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
-                      ey_stream_t stream) {
+static int nms_run(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+                   int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
+                   ey_stream_t stream, int mode) {
   EY_CHECK(pred && out_boxes && out_count && workspace, "nms: null pointer");
   EY_CHECK(B > 0 && nc > 0 && A > 0, "nms: bad extent");
-  EY_CHECK(conf_thres >= 0.f && conf_thres <= 1.f, "nms: Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", conf_thres);
-  EY_CHECK(iou_thres >= 0.f && iou_thres <= 1.f, "nms: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
   EY_CHECK(max_det > 0 && max_det <= 4096 && max_nms > 0, "nms: max_det=%d (1..4096) max_nms=%d", max_det, max_nms);
   multi_label = multi_label && nc > 1;  // ops.py:240
   EY_CHECK(workspace_bytes >= (multi_label ? ey_nms_workspace_bytes_ml(B, nc, A) : ey_nms_workspace_bytes(B, A)) && ey_aligned(workspace, 8),
@@ -866,7 +891,35 @@ extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres,
       hipLaunchKernelGGL(nms_score_kernel, dim3((unsigned)(P / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, cls_id, (int)P);
   }
   EY_LAUNCH_CHECK("ey_nms(score)");
-  return nms_select_launch(B, nc, A, P, P, multi_label, pred, (long)(4 + nc) * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, st);
+  return nms_select_launch(B, nc, A, P, P, multi_label, pred, (long)(4 + nc) * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, st, mode);
+}
+
+extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
+                      int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count, int32_t* out_index, void* workspace, size_t workspace_bytes,
+                      ey_stream_t stream) {
+  EY_CHECK(conf_thres >= 0.f && conf_thres <= 1.f, "nms: Invalid Confidence threshold %f, valid values are between 0.0 and 1.0", conf_thres);
+  EY_CHECK(iou_thres >= 0.f && iou_thres <= 1.f, "nms: Invalid IoU %f, valid values are between 0.0 and 1.0", iou_thres);
+  return nms_run(B, nc, A, pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, multi_label, class_mask, out_boxes, out_count, out_index, workspace,
+                 workspace_bytes, stream, 0);
+}
+
+// ---- Detect.postprocess (head.py:167-189) of the end2end heads: the k = min(max_det, A) best (anchor, class) pairs of every image in
+// descending score order, rows [x1,y1,x2,y2,score,class].  The reference takes the k anchors with the best class score and then the k
+// best pairs among them; every one of the k best pairs overall belongs to such an anchor (fewer than k pairs, hence fewer than k
+// anchors, beat it), so both are the k best pairs overall -- which is the multi-label candidate selection of the NMS kernel (radix
+// descent over the A*nc score keys, register / LDS sort) with the suppression switched off.  Equal scores: lower anchor, then lower
+// class first (torch.topk leaves that order unspecified).
+extern "C" size_t ey_e2e_topk_workspace_bytes(int B, int nc, int A) {
+  return (nc > 1 ? ey_nms_workspace_bytes_ml(B, nc, A) : ey_nms_workspace_bytes(B, A)) + (((size_t)B * 4 + 15) & ~(size_t)15);
+}
+extern "C" int ey_e2e_topk(int B, int nc, int A, const float* pred_xyxy, int k, float* out_rows, int32_t* out_index, void* workspace, size_t workspace_bytes,
+                           ey_stream_t stream) {
+  EY_CHECK(k > 0 && k <= 4096 && k <= A, "e2e_topk: k=%d (1..min(4096, A=%d))", k, A);
+  EY_CHECK(workspace && ey_aligned(workspace, 16) && workspace_bytes >= ey_e2e_topk_workspace_bytes(B, nc, A), "e2e_topk: workspace too small");
+  const size_t cnt_bytes = ((size_t)B * 4 + 15) & ~(size_t)15;
+  int32_t* count = (int32_t*)workspace;  // (always k: there are A*nc >= k pairs; kept for the shared kernel's interface)
+  return nms_run(B, nc, A, pred_xyxy, -1.f, 1.f, k, 0x7fffffff, 0.f, 1, 1, nullptr, out_rows, count, out_index, (char*)workspace + cnt_bytes, workspace_bytes - cnt_bytes,
+                 stream, NMS_MODE_XYXY | NMS_MODE_TOPK);
 }
 
 extern "C" int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,

@@ -18,6 +18,9 @@ class Model(torch.nn.Module):
         self.overrides = {}
         self.ckpt_path = None
         self.task = task
+        if isinstance(model, dict):  # (extension) an already loaded YAML dict
+            self._new(model, task=task, verbose=verbose, nc=nc)
+            return
         model = str(model).strip()
         if Path(model).suffix in {".yaml", ".yml"}:
             self._new(model, task=task, verbose=verbose, nc=nc)

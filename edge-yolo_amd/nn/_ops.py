@@ -532,10 +532,10 @@ def nms_candidates(cand, iou_thres, max_det, max_nms, max_wh, agnostic):
     return boxes, count, index
 
 
-def head_decode_levels(levels, pred, nms=None):
+def head_decode_levels(levels, pred, nms=None, xyxy=False):
     """levels: list (<= 4) of (box, cls, stride, q-or-None, a_off) -> every level of the fused DGQP + DFL + decode in ONE launch.
     nms = (conf_thres, class_mask uint8 tensor or None, classes): also build the NMS candidates in the same pass (pred may then be None);
-    returns a Candidates object."""
+    returns a Candidates object.  xyxy: rows 0-3 = x1,y1,x2,y2 (end2end heads, reference head.py:163-165)."""
     n = len(levels)
     box0, cls0 = levels[0][0], levels[0][1]
     L.require_device(box0, "head_decode")
@@ -563,8 +563,28 @@ def head_decode_levels(levels, pred, nms=None):
                                                       buf.data_ptr(), nb, L.stream()), "ey_head_decode_levels_nms")
         return Candidates(buf, B, nc, A, conf, classes, pred)
     with _tr("head_decode_kernel", nbytes, flops, note=f"{n} levels"):
-        L.check(L.lib().ey_head_decode_levels(L.dtype_code(box0.dtype), B, n, Hs, Ws, st, boxp, boxcs, clsp, clscs, nc, qa[0], qa[1], qa[2], qa[3], hid,
-                                              pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")
+        fn = L.lib().ey_head_decode_levels_xyxy if xyxy else L.lib().ey_head_decode_levels
+        L.check(fn(L.dtype_code(box0.dtype), B, n, Hs, Ws, st, boxp, boxcs, clsp, clscs, nc, qa[0], qa[1], qa[2], qa[3], hid,
+                   pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")
+
+
+def e2e_topk(pred, k, want_index=False):
+    """Detect.postprocess (reference head.py:167-189): pred fp32 (B,4+nc,A) with x1y1x2y2 rows -> (B,k,6) fp32 rows
+    [x1,y1,x2,y2,score,class], the k best (anchor, class) pairs per image in descending score order."""
+    L.require_device(pred, "e2e_topk")
+    if pred.dtype != torch.float32 or not pred.is_contiguous():
+        raise ValueError("e2e_topk: pred must be a contiguous float32 (B,4+nc,A) tensor")
+    B, no, A = pred.shape
+    nc = no - 4
+    if not 0 < k <= A:
+        raise ValueError(f"e2e_topk: k={k} must be in 1..A={A}")
+    out = torch.empty((B, k, 6), dtype=torch.float32, device=pred.device)
+    index = torch.empty((B, k), dtype=torch.int32, device=pred.device) if want_index else None
+    nb = L.lib().ey_e2e_topk_workspace_bytes(B, nc, A)
+    ws = torch.empty(nb, dtype=torch.uint8, device=pred.device)
+    with _tr("e2e_topk(score+select)", pred.numel() * 4 + out.numel() * 4):
+        L.check(L.lib().ey_e2e_topk(B, nc, A, pred.data_ptr(), k, out.data_ptr(), index.data_ptr() if want_index else None, ws.data_ptr(), nb, L.stream()), "ey_e2e_topk")
+    return (out, index) if want_index else out
 
 
 def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None, multi_label=False):

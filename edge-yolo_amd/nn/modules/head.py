@@ -1,8 +1,9 @@
-"""Detection heads, HIP-backed: `Detect` (reference head.py:38-189), `GF2Detect` (:194-345), `GFLHeadv2_uniH`
-(:827-908).  Same constructor signatures / attribute names / state_dict keys.  The towers are MFMA convs and
+"""Detection heads, HIP-backed: `Detect` (reference head.py:38-189), `GF2Detect` (:194-345), `E2EDetect` (:799-824),
+`GFLHeadv2_uniH` (:827-908).  Same constructor signatures / attribute names / state_dict keys.  The towers are MFMA convs and
 depthwise kernels; everything after them (DGQP statistics + quality FCs, DFL softmax-expectation, anchor decode,
 score modulation) is ONE fused kernel per pyramid level writing the (B, 4+nc, A) fp32 prediction tensor.
 """
+import copy
 import math
 
 import torch
@@ -13,7 +14,7 @@ from .conv import Conv, DWConv, _Packed, fold_bn
 from .. import _ops as ops
 from ... import _lib as L
 
-__all__ = ("Detect", "GF2Detect", "GFLHeadv2_uniH")
+__all__ = ("Detect", "GF2Detect", "E2EDetect", "GFLHeadv2_uniH")
 
 
 class _Plain(_Packed):
@@ -72,6 +73,9 @@ class Detect(nn.Module):
                 for x in ch)
         )
         self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+        if self.end2end:  # head.py:76-78
+            self.one2one_cv2 = copy.deepcopy(self.cv2)
+            self.one2one_cv3 = copy.deepcopy(self.cv3)
         self._tails = {}
         # packed tails / quality-head weights are caches of parameters: drop them whenever parameters are (re)loaded
         self.register_load_state_dict_post_hook(lambda m, _keys: m._reset_caches())
@@ -94,14 +98,17 @@ class Detect(nn.Module):
         self._reset_caches()
         return super()._apply(fn, *a, **k)
 
+    # branch of the towers the inference decodes: "" (cv2 / cv3 / reg_conf) or "one2one_" (their end2end copies, head.py:76-78,220-221)
+    _branch = ""
+
     def _box_tower(self, i, x, raw):
         """box logits -> raw[:, :64]."""
-        b = self.cv2[i]
+        b = getattr(self, self._branch + "cv2")[i]
         self._tail(b[2]).run(b[1](b[0](x)), raw[:, :4 * self.reg_max])
 
     def _cls_tower(self, i, x, raw):
         """class logits -> raw[:, 64:]."""
-        c = self.cv3[i]
+        c = getattr(self, self._branch + "cv3")[i]
         t = x
         out = raw[:, 4 * self.reg_max:]
         last = c[-2]
@@ -162,13 +169,13 @@ class Detect(nn.Module):
         (predict pipelines): the decode also builds the NMS candidates for that confidence threshold / class filter in the same pass
         and returns (_ops.Candidates, raw maps) -- `utils.ops.nms_device` takes it in place of `pred`, which is then neither written nor
         re-read (keep_pred=True still writes it, as Candidates.pred)."""
-        if self.end2end:
-            raise NotImplementedError("end2end (NMS-free) heads are outside the built path")
         if self.training:
             raise RuntimeError("edge-yolo_amd implements the inference forward only: call model.eval()")
         if self.reg_max != 16:
             raise NotImplementedError("the decode kernel is built for reg_max=16")
         xs = [L.as_nhwc(t) for t in x]
+        if self.end2end:
+            return self._forward_end2end(x, xs)
         B, dev, dt = xs[0].shape[0], xs[0].device, xs[0].dtype
         A = sum(t.shape[2] * t.shape[3] for t in xs)
         want_pred = nms is None or nms.get("keep_pred") or not (len(xs) <= 4 and self.nc > 1)
@@ -241,6 +248,40 @@ class Detect(nn.Module):
         self._decode(levels, pred)
         return pred if self.export else (pred, x)
 
+    # ---- end2end (NMS-free) inference, reference head.py:93-115 (Detect) / :273-298 (GF2Detect)
+    one2many_in_inference = False  # the reference also runs the one2many towers in eval mode and returns their maps next to the result,
+    #                                where nothing reads them; True reproduces that ("one2many" is None otherwise)
+
+    def _branch_maps(self, xs, branch):
+        B, dev, dt = xs[0].shape[0], xs[0].device, xs[0].dtype
+        self.__dict__["_branch"] = branch
+        try:
+            raws, levels, a_off = [], [], 0
+            for i, t in enumerate(xs):
+                raw = L.empty_nhwc(B, (self.no + 7) // 8 * 8, t.shape[2], t.shape[3], dt, dev)[:, :self.no]
+                self._towers(i, t, raw)
+                levels.append((raw[:, :4 * self.reg_max], raw[:, 4 * self.reg_max:], self._stride_f[i], self._quality_params(i, dev), a_off))
+                a_off += t.shape[2] * t.shape[3]
+                raws.append(raw)
+        finally:
+            self.__dict__.pop("_branch", None)
+        return raws, levels, a_off
+
+    def _forward_end2end(self, x, xs):
+        """-> (y (B, min(max_det, A), 6) fp32 rows [x1,y1,x2,y2,score,class], {"one2many": maps or None, "one2one": maps}): the one2one
+        towers, the decode with x1y1x2y2 boxes (decode_bboxes: xywh and not end2end, head.py:163-165) and Detect.postprocess (:167-189)
+        as the top-k selection kernel -- no NMS follows (utils/ops.py:224-228 only filters these rows)."""
+        if len(xs) > 4:
+            raise NotImplementedError("end2end heads: at most 4 pyramid levels")
+        if getattr(self, "_stride_f", None) is None:
+            self._stride_f = [float(s) for s in self.stride]
+        raws, levels, A = self._branch_maps(xs, "one2one_")
+        pred = torch.empty((xs[0].shape[0], 4 + self.nc, A), dtype=torch.float32, device=xs[0].device)
+        ops.head_decode_levels(levels, pred, xyxy=True)
+        y = ops.e2e_topk(pred, min(self.max_det, A))
+        many = self._branch_maps(xs, "")[0] if self.one2many_in_inference else None
+        return y if self.export else (y, {"one2many": many, "one2one": raws})
+
     def _decode(self, levels, pred):
         # every level is decoded by ONE launch (reference: Detect._inference runs after all towers, head.py:84-90,117-148)
         if len(levels) <= 4:
@@ -279,6 +320,8 @@ class GF2Detect(Detect):
         self.reg_conf = nn.ModuleList(
             nn.Sequential(nn.Conv2d(in_stat, self.reg_channels, 1, bias=True), nn.ReLU(inplace=True), nn.Conv2d(self.reg_channels, 1, 1, bias=True),
                           nn.Sigmoid()) for _ in ch)
+        if self.end2end:  # head.py:220-221
+            self.one2one_reg_conf = copy.deepcopy(self.reg_conf)
         self._qcache = {}
 
     def _quality_params(self, i, device):
@@ -286,12 +329,28 @@ class GF2Detect(Detect):
             return None
         if self.reg_topk != 4 or not self.add_mean:
             raise NotImplementedError("the decode kernel is built for reg_topk=4, add_mean=True (the reference defaults)")
-        q = self._qcache.get((i, device))
+        q = self._qcache.get((self._branch, i, device))
         if q is None:
-            m = self.reg_conf[i]
+            m = getattr(self, self._branch + "reg_conf")[i]
             f = lambda t: t.detach().float().to(device).contiguous()  # noqa: E731
-            q = self._qcache[(i, device)] = (f(m[0].weight).view(m[0].out_channels, -1), f(m[0].bias), f(m[2].weight).view(-1), f(m[2].bias))
+            q = self._qcache[(self._branch, i, device)] = (f(m[0].weight).view(m[0].out_channels, -1), f(m[0].bias), f(m[2].weight).view(-1), f(m[2].bias))
         return q
+
+
+class E2EDetect(GF2Detect):
+    """NMS-free head (reference head.py:799-824): GF2Detect with end2end = True -- one2one copies of both towers and of the quality
+    head (:76-78,220-221), decoded as x1y1x2y2 and reduced to the max_det best rows by Detect.postprocess (:167-189, :273-298).  The
+    class tower is the depthwise structure whatever `legacy` says (:812-822)."""
+
+    end2end = True
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__(nc, ch)
+        c3 = max(ch[0], min(self.nc, 100))
+        self.cv3 = nn.ModuleList(
+            nn.Sequential(nn.Sequential(DWConv(x, x, 3), Conv(x, c3, 1)), nn.Sequential(DWConv(c3, c3, 3), Conv(c3, c3, 1)), nn.Conv2d(c3, self.nc, 1))
+            for x in ch)
+        self.one2one_cv3 = copy.deepcopy(self.cv3)
 
 
 class GFLHeadv2_uniH(GF2Detect):

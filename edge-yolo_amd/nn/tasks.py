@@ -13,7 +13,7 @@ import torch.nn as nn
 import yaml
 
 from . import _ops as ops
-from .modules import (C2PSA, C2PSA_LinearAttention, C2f, C3, C3k2, Concat, Conv, DSC3K2_Wavelet, DSConv, DWConv, Detect, GF2Detect,
+from .modules import (C2PSA, C2PSA_LinearAttention, C2f, C3, C3k2, Concat, Conv, DSC3K2_Wavelet, DSConv, DWConv, Detect, E2EDetect, GF2Detect,
                       GFLHeadv2_uniH, SPPF, Upsample)
 from .modules import *  # noqa: F401,F403  (registry: YAML names resolve through globals(), as in the reference)
 from .modules.conv import _Packed
@@ -23,7 +23,7 @@ from ..utils.ops import make_divisible
 CFG_DIR = Path(__file__).resolve().parent.parent / "cfg" / "models"
 _CH_MODULES = {Conv, SPPF, C2PSA, C2PSA_LinearAttention, DWConv, C2f, C3k2, DSC3K2_Wavelet, C3, DSConv}
 _REPEAT_MODULES = {C2f, C3k2, DSC3K2_Wavelet, C3, C2PSA, C2PSA_LinearAttention}
-_HEADS = {Detect, GF2Detect, GFLHeadv2_uniH}
+_HEADS = {Detect, GF2Detect, E2EDetect, GFLHeadv2_uniH}
 
 
 def guess_model_scale(model_path):

@@ -46,6 +46,33 @@ def scale_boxes(img1_shape, boxes, img0_shape, ratio_pad=None, padding=True, xyw
     return clip_boxes(boxes, img0_shape)
 
 
+_CLASS_TENSORS = {}
+
+
+def _end2end_filter(prediction, conf_thres, classes, max_det):
+    """Output of an end2end head, (B, k, 6) rows [x1,y1,x2,y2,score,class] (reference ops.py:224-228): no suppression, only
+    `pred[pred[:, 4] > conf][:max_det]` and then the class filter, here on fixed-size tensors (graph-capturable): kept rows are moved
+    to the front in their order, the rest zeroed.  Returns (boxes (B,max_det,6), count (B,) int32, index (B,max_det) int32 = source row)."""
+    p = prediction.float()
+    B, K, _ = p.shape
+    keep = p[..., 4] > conf_thres
+    keep &= (keep.cumsum(1) - 1) < max_det
+    if classes is not None:
+        key = (tuple(classes), p.device)
+        if key not in _CLASS_TENSORS:  # uploaded once per filter (never inside a captured graph after the first, eager, call)
+            _CLASS_TENSORS[key] = torch.as_tensor(list(classes), dtype=torch.float32, device=p.device)
+        keep &= (p[..., 5:6] == _CLASS_TENSORS[key]).any(-1)
+    order = torch.sort((~keep).to(torch.uint8), dim=1, stable=True).indices  # kept rows first, original (descending score) order
+    n = min(K, max_det)
+    boxes = torch.zeros((B, max_det, 6), dtype=torch.float32, device=p.device)
+    index = torch.full((B, max_det), -1, dtype=torch.int32, device=p.device)
+    sel = order[:, :n]
+    ok = torch.gather(keep, 1, sel)
+    boxes[:, :n] = torch.gather(p, 1, sel[..., None].expand(-1, -1, 6)) * ok[..., None]
+    index[:, :n] = torch.where(ok, sel.to(torch.int32), index[:, :n])
+    return boxes, keep.sum(1).to(torch.int32), index
+
+
 def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, max_det=300, nc=0, max_nms=30000, max_wh=7680,
                multi_label=False):
     """Batched NMS on the device, fixed-size outputs (graph-capturable): returns (boxes (B,max_det,6), count (B,),
@@ -67,6 +94,8 @@ def nms_device(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnost
         return _ops.nms_candidates(c, iou_thres, max_det, max_nms, max_wh, agnostic)
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
+    if prediction.shape[-1] == 6:
+        return _end2end_filter(prediction, conf_thres, classes, max_det)
     nc = nc or (prediction.shape[1] - 4)
     if prediction.shape[1] - nc - 4:
         raise NotImplementedError("mask/keypoint channels (nm>0) are outside the detect path")
@@ -92,8 +121,6 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         raise NotImplementedError("autolabel / rotated NMS variants are not part of the built path")
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
-    if prediction.shape[-1] == 6:
-        raise NotImplementedError("end-to-end (B,N,6) predictions need no NMS and are outside the built path")
     boxes, count, _ = nms_device(prediction, conf_thres, iou_thres, classes, agnostic, max_det, nc, max_nms, max_wh, multi_label)
     n = count.tolist()  # one D2H sync for the whole batch
     return [boxes[i, : n[i]] for i in range(len(n))]

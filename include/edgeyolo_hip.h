@@ -243,6 +243,21 @@ int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const
 int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
                       int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream);
 
+/* ---- End2end (NMS-free) heads: E2EDetect = GF2Detect with end2end=True (head.py:273-298,799-824).
+ * ey_head_decode_levels_xyxy: ey_head_decode_levels with rows 0-3 of pred = x1,y1,x2,y2 in input pixels (Detect.decode_bboxes passes
+ *   xywh = not end2end to dist2bbox, head.py:163-165, utils/tal.py:348-357); rows 4.. unchanged.
+ * ey_e2e_topk: Detect.postprocess (head.py:167-189) on that tensor: out_rows [B, k, 6] fp32 = the k best (anchor, class) pairs of each
+ *   image in descending score order, row = x1,y1,x2,y2,score,class; k = min(max_det, A) is the caller's; out_index [B, k] (anchor of
+ *   each row) or NULL.  Equal scores: lower anchor, then lower class first (torch.topk leaves that order unspecified).
+ *   workspace: ey_e2e_topk_workspace_bytes(B, nc, A) bytes, 16-byte aligned. */
+int ey_head_decode_levels_xyxy(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box,
+                               const int* box_cstride, const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1,
+                               const float* const* q_b1, const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred,
+                               int A_total, const int* a_off, ey_stream_t stream);
+size_t ey_e2e_topk_workspace_bytes(int B, int nc, int A);
+int ey_e2e_topk(int B, int nc, int A, const float* pred_xyxy, int k, float* out_rows, int32_t* out_index, void* workspace,
+                size_t workspace_bytes, ey_stream_t stream);
+
 /* ---- Block programs: a chain of layers on SMALL feature maps (<= 4096 pixels per image; built for the 20x20 part of the network at
  * 640x640: stride-2 Conv -> DSC3K2_Wavelet -> SPPF -> C2PSA_LinearAttention, nn/modules/block.py:204-223,3412-3497,3749-3788; the
  * last neck block; the 20x20 Detect towers, head.py:59-70) executed by ONE launch: one persistent 1024-thread workgroup per image

@@ -40,7 +40,7 @@ def load_yaml(path):  # nn/tasks.py:1150-1163  ("yolo11n-test.yaml" -> file "yol
 
 _CSP = {"C3k2", "DSC3K2_Wavelet", "C2PSA", "C2PSA_LinearAttention", "C2f", "C3"}
 _CH = _CSP | {"Conv", "SPPF", "DWConv", "DSConv"}
-_HEADS = {"Detect", "GF2Detect", "GFLHeadv2_uniH"}
+_HEADS = {"Detect", "GF2Detect", "GFLHeadv2_uniH", "E2EDetect"}
 
 
 def parse_graph(d, ch=3):
@@ -267,24 +267,50 @@ def dgqp(sd, p, box, reg_max=16, topk=4):
     return torch.sigmoid(F.conv2d(h, sd[p + ".2.weight"], sd[p + ".2.bias"]))
 
 
-def detect_head(sd, p, xs, nc, strides, quality, legacy=False, reg_max=16):
-    """Detect.forward/_inference head.py:81-148; GF2Detect._inference_with_quality :301-345;
-    GFLHeadv2_uniH.forward :880-908; DFL block.py:87-90; dist2bbox tal.py:348-357.
-    Returns (y (B,4+nc,A), raw list of (B,64+nc,H,W))."""
+def head_towers(sd, p, xs, quality, legacy=False, reg_max=16, br=""):
+    """cv2 / cv3 towers (+ DGQP) of one branch; br = "one2one_" selects the end2end copies (head.py:76-78,220-221)."""
     raw, quals = [], []
     for i, x in enumerate(xs):
-        t = conv(sd, f"{p}.cv2.{i}.0", x, 3)
-        t = conv(sd, f"{p}.cv2.{i}.1", t, 3)
-        box = F.conv2d(t, sd[f"{p}.cv2.{i}.2.weight"], sd[f"{p}.cv2.{i}.2.bias"])
+        t = conv(sd, f"{p}.{br}cv2.{i}.0", x, 3)
+        t = conv(sd, f"{p}.{br}cv2.{i}.1", t, 3)
+        box = F.conv2d(t, sd[f"{p}.{br}cv2.{i}.2.weight"], sd[f"{p}.{br}cv2.{i}.2.bias"])
         if legacy:  # head.py:64-65
-            u = conv(sd, f"{p}.cv3.{i}.1", conv(sd, f"{p}.cv3.{i}.0", x, 3), 3)
-        else:  # head.py:66-75
-            u = conv(sd, f"{p}.cv3.{i}.0.1", dwconv(sd, f"{p}.cv3.{i}.0.0", x, 3), 1)
-            u = conv(sd, f"{p}.cv3.{i}.1.1", dwconv(sd, f"{p}.cv3.{i}.1.0", u, 3), 1)
-        cls = F.conv2d(u, sd[f"{p}.cv3.{i}.2.weight"], sd[f"{p}.cv3.{i}.2.bias"])
+            u = conv(sd, f"{p}.{br}cv3.{i}.1", conv(sd, f"{p}.{br}cv3.{i}.0", x, 3), 3)
+        else:  # head.py:66-75 (E2EDetect builds the same DW structure itself, :812-822)
+            u = conv(sd, f"{p}.{br}cv3.{i}.0.1", dwconv(sd, f"{p}.{br}cv3.{i}.0.0", x, 3), 1)
+            u = conv(sd, f"{p}.{br}cv3.{i}.1.1", dwconv(sd, f"{p}.{br}cv3.{i}.1.0", u, 3), 1)
+        cls = F.conv2d(u, sd[f"{p}.{br}cv3.{i}.2.weight"], sd[f"{p}.{br}cv3.{i}.2.bias"])
         if quality:
-            quals.append(dgqp(sd, f"{p}.reg_conf.{i}", box, reg_max))
+            quals.append(dgqp(sd, f"{p}.{br}reg_conf.{i}", box, reg_max))
         raw.append(torch.cat((box, cls), 1))
+    return raw, quals
+
+
+def e2e_postprocess(preds, max_det, nc):
+    """Detect.postprocess, head.py:167-189: preds (B, A, 4+nc) -> (B, min(max_det, A), 6) = [box(4), score, class].  Two top-k passes:
+    the k anchors with the best class score, then the k best (anchor, class) pairs among them.  (Equal scores: torch.topk's order.)"""
+    B, A, _ = preds.shape
+    boxes, scores = preds.split([4, nc], dim=-1)
+    k = min(max_det, A)
+    index = scores.amax(dim=-1).topk(k)[1].unsqueeze(-1)
+    boxes = boxes.gather(dim=1, index=index.repeat(1, 1, 4))
+    scores = scores.gather(dim=1, index=index.repeat(1, 1, nc))
+    scores, index = scores.flatten(1).topk(k)
+    i = torch.arange(B)[..., None]
+    return torch.cat([boxes[i, index // nc], scores[..., None], (index % nc)[..., None].float()], dim=-1)
+
+
+def detect_head(sd, p, xs, nc, strides, quality, legacy=False, reg_max=16, e2e=False, max_det=300):
+    """Detect.forward/_inference head.py:81-148; GF2Detect._inference_with_quality :301-345;
+    GFLHeadv2_uniH.forward :880-908; DFL block.py:87-90; dist2bbox tal.py:348-357.
+    Returns (y (B,4+nc,A), raw list of (B,64+nc,H,W)).
+    e2e (E2EDetect = GF2Detect with end2end=True, head.py:273-298,799-824): the one2one branch is decoded, boxes stay x1y1x2y2
+    (decode_bboxes: xywh and not end2end, :163-165), then Detect.postprocess; returns (y (B,k,6), {"one2many": maps, "one2one": maps})."""
+    if e2e:
+        raw, quals = head_towers(sd, p, xs, quality, False, reg_max, "one2one_")
+        many, _ = head_towers(sd, p, xs, False, False, reg_max, "")
+    else:
+        raw, quals = head_towers(sd, p, xs, quality, legacy, reg_max)
     B = raw[0].shape[0]
     no = nc + 4 * reg_max
     x_cat = torch.cat([r.view(B, no, -1) for r in raw], 2)
@@ -296,12 +322,15 @@ def detect_head(sd, p, xs, nc, strides, quality, legacy=False, reg_max=16):
     d = F.conv2d(d, sd[p + ".dfl.conv.weight"]).view(B, 4, A)  # expectation over bins
     lt, rb = d.chunk(2, 1)
     x1y1, x2y2 = anchors.unsqueeze(0) - lt, anchors.unsqueeze(0) + rb
-    dbox = torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1) * st
+    dbox = (torch.cat((x1y1, x2y2), 1) if e2e else torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), 1)) * st
     prob = cls.sigmoid()
     if quality:
         q = torch.cat([t.view(B, 1, -1) for t in quals], 2)
         prob = prob * q.clamp(1e-6, 1 - 1e-6)
-    return torch.cat((dbox, prob), 1), raw
+    y = torch.cat((dbox, prob), 1)
+    if e2e:
+        return e2e_postprocess(y.permute(0, 2, 1), max_det, nc), {"one2many": many, "one2one": raw}
+    return y, raw
 
 
 # --------------------------------------------------------------------------- whole model
@@ -334,7 +363,7 @@ class OracleModel:
         if t == "Concat":
             return torch.cat(x, a[0])
         if t in _HEADS:
-            return detect_head(sd, p, x, self.nc, self.stride, t != "Detect", self.legacy)
+            return detect_head(sd, p, x, self.nc, self.stride, t != "Detect", self.legacy, e2e=t == "E2EDetect")
         raise NotImplementedError(t)
 
     @torch.no_grad()

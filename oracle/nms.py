@@ -59,6 +59,11 @@ def non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, classes=None, agn
     With return_idx=True also returns, per image, the anchor index of every kept row (single-label only)."""
     pred = np.asarray(pred, F32)
     assert 0 <= conf_thres <= 1 and 0 <= iou_thres <= 1  # ops.py:217-218
+    if pred.shape[-1] == 6:  # ops.py:224-228: output of an end-to-end head (B, k, 6) -- confidence / class filter only, no suppression
+        out = [p[p[:, 4] > F32(conf_thres)][:max_det] for p in pred]
+        if classes is not None:
+            out = [p[np.isin(p[:, 5], np.asarray(classes, F32))] for p in out]
+        return out
     bs = pred.shape[0]
     nc = nc or pred.shape[1] - 4
     mi = 4 + nc

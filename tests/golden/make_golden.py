@@ -290,7 +290,41 @@ def validator_case():
     print("validator", dict(res), "tp", int(tp.sum()), "labels", len(cls))
 
 
+def e2e_case():
+    """E2EDetect (reference head.py:273-298,799-824; no YAML of the reference names it): the EdgeLine-n graph with its head entry renamed,
+    built by the reference's own parse_model.  Inference output = Detect.postprocess top-k rows (B, 300, 6) [x1,y1,x2,y2,score,cls]
+    of the one2one branch, plus the raw maps of both branches; the predict-time filter of non_max_suppression (ops.py:224-228)."""
+    import yaml
+    from ultralytics.nn.tasks import yaml_model_load
+    d = yaml_model_load("yolo11n-test.yaml")
+    assert d["head"][-1][2] in ("GFLHeadv2_uniH", "GF2Detect", "Detect"), d["head"][-1]
+    d["head"][-1][2] = "E2EDetect"
+    m = DetectionModel(d, ch=3, nc=80, verbose=False).eval()
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(synth.synth_state_dict(shapes, gain=1.9))
+    nparams = sum(p.numel() for p in m.parameters())
+    m.fuse(verbose=False)
+    x = synth.synth_images(2, 128, 160, seed=3)
+    y, aux = m(x)
+    out = dict(y=y.numpy(), stride=np.array([float(s) for s in m.stride]), nkeys=np.int64(len(shapes)), params=np.int64(nparams))
+    for br in ("one2one", "one2many"):
+        for i, r in enumerate(aux[br]):
+            out[f"{br}{i}"] = r.numpy()
+    det = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, classes=None)
+    detc = rops.non_max_suppression(y.clone(), 0.05, 0.7, max_det=20, classes=[int(y[0, 0, 5]), int(y[1, 3, 5])])
+    for i in range(2):
+        out[f"det{i}"] = det[i].numpy()
+        out[f"detc{i}"] = detc[i].numpy()
+    out["detc_classes"] = np.array([int(y[0, 0, 5]), int(y[1, 3, 5])])
+    out["state_shapes"] = np.array(json.dumps({k: list(v) for k, v in shapes.items() if "one2one" in k or k.startswith("model.23.cv3.0")}))
+    np.savez_compressed(os.path.join(HERE, "e2e_128x160.npz"), **out)
+    print("e2e", y.shape, [tuple(r.shape) for r in aux["one2one"]], [len(t) for t in det], [len(t) for t in detc], float(y[0, 0, 4]), float(y[0, -1, 4]))
+
+
 if __name__ == "__main__":
+    if "--e2e-only" in sys.argv:
+        e2e_case()
+        sys.exit(0)
     if "--validator-only" in sys.argv:
         validator_case()
         sys.exit(0)
@@ -306,6 +340,7 @@ if __name__ == "__main__":
     nms_cases()
     metrics_cases()
     validator_case()
+    e2e_case()
     model_small("yolo11n-test.yaml", "edgeline_n_64")
     model_small("yolo11n.yaml", "yolo11n_64")
     for abl in ("GF2Detect", "lineattention", "DSC3K2_Wavelet", "tune"):

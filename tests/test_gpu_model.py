@@ -379,3 +379,73 @@ def test_nc10_model_and_chain_vs_oracle(E, cfg_dir):
     torch.cuda.synchronize()
     assert float((y_chain[:, 4:] - y_plain[:, 4:]).abs().max()) < 2e-3 and float((y_chain[:, :4] - y_plain[:, :4]).abs().max()) < 0.25
     assert float((y_chain[:, 4:].cpu() - want[:, 4:]).abs().max()) < 2e-2
+
+
+def _e2e_yaml():
+    from edge_yolo_amd.nn.tasks import yaml_model_load
+    d = yaml_model_load("yolo11n-test.yaml")
+    d["head"][-1][2] = "E2EDetect"
+    return d
+
+
+def test_e2e_detect_vs_reference_golden(E, golden_dir):
+    """SURVEY 8f-4, NMS-free head: E2EDetect (reference head.py:273-298,799-824) on the EdgeLine-n graph against the REFERENCE's forward
+    (tests/golden/e2e_128x160.npz: its y (B,300,6) top-k rows, the raw maps of both branches, and the end-to-end branch of
+    non_max_suppression).  fp32 bar 1e-3 on boxes / scores; the row order may differ only where two scores sit within fp32 noise."""
+    from edge_yolo_amd.nn.tasks import DetectionModel
+    from edge_yolo_amd.utils import ops as uops
+    g = np.load(os.path.join(golden_dir, "e2e_128x160.npz"))
+    m = DetectionModel(_e2e_yaml())
+    assert m.end2end and len(m.state_dict()) == int(g["nkeys"]) and sum(p.numel() for p in m.parameters()) == int(g["params"])
+    for k, v in json.loads(str(g["state_shapes"])).items():
+        assert tuple(m.state_dict()[k].shape) == tuple(v), k
+    assert [float(s) for s in m.stride] == [float(s) for s in g["stride"]]
+    m.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}))
+    m = m.cuda().fuse().float().eval()
+    m.model[-1].one2many_in_inference = True
+    x = synth.synth_images(2, 128, 160, seed=3).cuda()
+    y, aux = m(x)
+    assert tuple(y.shape) == (2, 300, 6)
+    for br in ("one2one", "one2many"):
+        for i, r in enumerate(aux[br]):
+            np.testing.assert_allclose(r.float().cpu().numpy(), g[f"{br}{i}"], rtol=1e-4, atol=3e-4)
+    y = y.cpu().numpy()
+    np.testing.assert_allclose(y[..., 4], g["y"][..., 4], rtol=1e-4, atol=1e-5)
+    assert (np.diff(y[..., 4], axis=1) <= 0).all()
+    same = y[..., 5] == g["y"][..., 5]
+    assert same.mean() > 0.99
+    np.testing.assert_allclose(y[..., :4][same], g["y"][..., :4][same], rtol=1e-4, atol=1e-3)
+    # the predict-time filter (ops.py:224-228) on the reference's own rows: exact
+    gy = torch.tensor(g["y"]).cuda()
+    for conf, md, cl, key in ((0.25, 300, None, "det"), (0.05, 20, [int(c) for c in g["detc_classes"]], "detc")):
+        out = uops.non_max_suppression(gy, conf, 0.7, classes=cl, max_det=md)
+        for i in range(2):
+            np.testing.assert_array_equal(out[i].cpu().numpy(), g[f"{key}{i}"])
+    # f16 throughput mode, and the top-k kernel against the oracle's two-pass selection on the SAME prediction tensor (bit-exact rows)
+    mh = m.half()
+    yh, _ = mh(x.half())
+    assert float((yh[..., 4].float().cpu() - torch.tensor(g["y"][..., 4])).abs().max()) < 2e-2
+    from edge_yolo_amd.nn import _ops
+    pred = synth.synth_pred(3, 80, 8400, seed=4, dense=True).cuda()
+    rows, idx = _ops.e2e_topk(pred, 300, want_index=True)
+    want = om.e2e_postprocess(pred.cpu().permute(0, 2, 1), 300, 80)
+    np.testing.assert_array_equal(rows.cpu().numpy(), want.numpy())
+    np.testing.assert_array_equal(pred.cpu().numpy()[np.arange(3)[:, None], :4, idx.cpu().numpy()], want.numpy()[..., :4])
+    rows1 = _ops.e2e_topk(pred[:, :5].contiguous(), 300)  # nc = 1
+    np.testing.assert_array_equal(rows1.cpu().numpy(), om.e2e_postprocess(pred[:, :5].cpu().permute(0, 2, 1), 300, 1).numpy())
+
+
+def test_e2e_predict_surface(E):
+    """YOLO(...).predict() on an end2end model: no NMS stage, rows = the head's top-k filtered by conf / classes / max_det; graph replay
+    equals eager."""
+    model = E.YOLO(_e2e_yaml())
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    x = synth.synth_images(2, 128, 160, seed=3)
+    r1 = model.predict(x, conf=0.3, iou=0.7, device="cuda:0", graph=False, max_det=50)
+    r2 = model.predict(x, conf=0.3, iou=0.7, device="cuda:0", graph=True, max_det=50)
+    y, _ = model.model.float()(x.cuda())
+    for i, (a, b) in enumerate(zip(r1, r2)):
+        np.testing.assert_array_equal(a.boxes.data.cpu().numpy(), b.boxes.data.cpu().numpy())
+        want = onms.non_max_suppression(y[i:i + 1].cpu().numpy(), 0.3, 0.7, max_det=50)[0]
+        assert len(a.boxes.data) == len(want) and 0 < len(want) <= 50
+        np.testing.assert_allclose(a.boxes.data.cpu().numpy()[:, 4], want[:, 4], atol=2e-2)

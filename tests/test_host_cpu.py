@@ -239,3 +239,19 @@ print(ex.export({ref_pt!r}, {out_pt!r}))
             torch.testing.assert_close(got[k].float(), v.half().float(), rtol=0, atol=0)
         else:
             assert torch.equal(got[k], v)
+
+
+def test_e2e_detect_structure_matches_reference(golden_dir):
+    """E2EDetect (reference head.py:799-824) builds the reference's state_dict: one2one copies of both towers and the quality head."""
+    import json
+    import edge_yolo_amd  # noqa: F401
+    from edge_yolo_amd.nn.tasks import DetectionModel, yaml_model_load
+    g = np.load(os.path.join(golden_dir, "e2e_128x160.npz"))
+    d = yaml_model_load("yolo11n-test.yaml")
+    d["head"][-1][2] = "E2EDetect"
+    m = DetectionModel(d)
+    sd = m.state_dict()
+    assert m.end2end and len(sd) == int(g["nkeys"]) and sum(p.numel() for p in m.parameters()) == int(g["params"])
+    for k, v in json.loads(str(g["state_shapes"])).items():
+        assert tuple(sd[k].shape) == tuple(v), k
+    assert [float(s) for s in m.stride] == [float(s) for s in g["stride"]]

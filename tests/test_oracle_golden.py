@@ -185,3 +185,34 @@ def test_model_large_scales(cfg_dir, golden_dir, name, tag):
     torch.testing.assert_close(y, g["y"], rtol=1e-4, atol=2e-4)
     for i, r in enumerate(raw):
         torch.testing.assert_close(r, g[f"raw{i}"], **TOL)
+
+
+def _e2e_oracle(cfg_dir, golden_dir, structure):
+    g = np.load(os.path.join(golden_dir, "e2e_128x160.npz"))
+    shapes = {k: tuple(v) for k, v in structure["yolo11n-test.yaml"]["state_shapes"].items()}
+    shapes.update({k: tuple(v) for k, v in json.loads(str(g["state_shapes"])).items()})
+    assert len(shapes) == int(g["nkeys"])
+    d = om.load_yaml(os.path.join(cfg_dir, "yolo11n-test.yaml"))
+    d["head"][-1][2] = "E2EDetect"
+    return g, om.OracleModel(d, synth.synth_state_dict(shapes))
+
+
+def test_e2e_detect(cfg_dir, golden_dir, structure):
+    """E2EDetect (head.py:273-298,799-824): one2one branch, x1y1x2y2 decode, Detect.postprocess top-k; then the end-to-end branch of
+    non_max_suppression (ops.py:224-228).  Golden: the reference's own forward on the EdgeLine-n graph with the head entry renamed."""
+    g, o = _e2e_oracle(cfg_dir, golden_dir, structure)
+    y, aux = o(synth.synth_images(2, 128, 160, seed=3))
+    assert tuple(y.shape) == (2, 300, 6)
+    for br in ("one2one", "one2many"):
+        for i, r in enumerate(aux[br]):
+            torch.testing.assert_close(r, torch.tensor(g[f"{br}{i}"]), **TOL)
+    gy = torch.tensor(g["y"])
+    torch.testing.assert_close(y[..., 4], gy[..., 4], rtol=1e-4, atol=1e-6)     # scores, descending
+    assert (y[..., 5] == gy[..., 5]).float().mean() > 0.99                      # same (anchor, class) pairs up to fp32-noise swaps
+    same = y[..., 5] == gy[..., 5]
+    torch.testing.assert_close(y[..., :4][same], gy[..., :4][same], rtol=1e-4, atol=2e-4)
+    det = onms.non_max_suppression(g["y"], 0.25, 0.7, max_det=300)
+    detc = onms.non_max_suppression(g["y"], 0.05, 0.7, max_det=20, classes=[int(c) for c in g["detc_classes"]])
+    for i in range(2):
+        np.testing.assert_array_equal(det[i], g[f"det{i}"])
+        np.testing.assert_array_equal(detc[i], g[f"detc{i}"])
