@@ -429,6 +429,42 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
       }
     }
     int kofs = 0;
+    if (KS == 3 && p.nsrc == 1 && p.srcC[0] <= 128) {
+      // 3x3, one source of <= 128 channels (the stride-2 downsampling convs): a tap is ONE batch of <= 4 k-steps whose pixel fragments
+      // come straight from global memory -- nine dependent round trips per tile when each batch is requested only after the previous
+      // one was multiplied.  Here tap t+1 is in flight while tap t runs (two fragment buffers, statically alternated).
+      const int Cs = p.srcC[0];
+      Vec8<T> bq[2][MT][4];
+      auto issue_tap = [&](int tap, Vec8<T> (&bf)[MT][4]) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int tapoff = (ky * p.W + kx) * p.srcCs[0] * (int)sizeof(T);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int iy = poy[mt] * p.stride - p.pad + ky, ix = pox[mt] * p.stride - p.pad + kx;
+          const bool inb = pv[mt] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            BufLoad8<T>::load(bf[mt][ks], rs[0], (inb && (ks * 32 + 8 * g) < Cs) ? (unsigned)(base[0][mt] + tapoff + ks * 32 * (int)sizeof(T)) : EY_OOB);
+        }
+      };
+      issue_tap(0, bq[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) issue_tap(tap + 1, bq[(tap + 1) & 1]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (ks * 32 < Cs) {
+            Vec8<T> af[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) af[nt].load(wlane + nt * 16 * p.LSw + tap * Cs + ks * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bq[tap & 1][mt][ks], acc[mt][nt]);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
 #pragma unroll
@@ -476,6 +512,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
           }
         }
       }
+    }
     }
 
     // ---- epilogue
