@@ -167,13 +167,17 @@ def choose_variant(variants, trial, reduce_max):
     return best, objs[best], times
 
 
-def api_throughput(name, sd, nc, batch, imgsz, half, steps, warmup, conf, iou, max_det, device):
-    """images/s through the public API: YOLO.predict_batches with pinned HOST tensors in and Results out (PCIe upload included)."""
+def api_throughput(name, sd, nc, batch, imgsz, half, steps, warmup, conf, iou, max_det, device, u8=False):
+    """images/s through the public API: YOLO.predict_batches with pinned HOST tensors in and Results out (PCIe upload included).
+    u8: decoded image batches (uint8 (B,H,W,3) BGR) instead of normalised float tensors -- converted on the device."""
     import edge_yolo_amd
     y = edge_yolo_amd.YOLO(name, nc=nc)
     y.model.load_state_dict(sd)
-    dt = torch.float16 if half else torch.float32
-    x = torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(0)).to(dt).pin_memory()
+    dt = torch.uint8 if u8 else torch.float16 if half else torch.float32
+    if u8:
+        x = torch.randint(0, 256, (batch, imgsz, imgsz, 3), generator=torch.Generator().manual_seed(0), dtype=torch.uint8).pin_memory()
+    else:
+        x = torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(0)).to(dt).pin_memory()
     total = warmup + steps
     t0, n, ndet = None, 0, 0
     for res in y.predict_batches((x for _ in range(total)), half=half, conf=conf, iou=iou, max_det=max_det, device=device):
@@ -273,7 +277,7 @@ def main():
                 last = stages.pop()
                 stages.append(lambda stt, last=last: post(last(stt)))
             pipe = PipelinedRunner(*stages, images, streams=shared_streams)
-            for j in range(pipe.n):
+            for j in range(pipe.nsets):
                 pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
             pipe.cuts = list(cuts)
             return pipe
@@ -333,6 +337,7 @@ def main():
             del pipe, step, drain
         torch.cuda.empty_cache()
         out["predict_batches"] = api_throughput(a.model, sd, a.nc, a.batch, a.imgsz, a.dtype == "f16", min(a.steps, 40), 8, conf, iou, max_det, dev)
+        out["predict_batches_u8"] = api_throughput(a.model, sd, a.nc, a.batch, a.imgsz, a.dtype == "f16", min(a.steps, 40), 8, conf, iou, max_det, dev, u8=True)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou, nc=a.nc)
     if rank == 0:

@@ -625,10 +625,12 @@ __device__ __forceinline__ LbCoef lb_coef(int d, double scale, int ssize) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int sh, int sw, int srow, T* __restrict__ dst, int H, int W,
+__global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restrict__ src, int sh, int sw, int srow, long src_img, T* __restrict__ dst, int H, int W,
                                                         int nh, int nw, int top, int left, int pad, int swap_rb, double scale_x, double scale_y) {
   const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
   if (x >= W) return;
+  src += (long)blockIdx.z * src_img;       // image blockIdx.z of a batch of same-shape images (ey_letterbox_batch)
+  dst += (long)blockIdx.z * 3 * H * W;
   int v[3] = {pad, pad, pad};
   const int dx = x - left, dy = y - top;
   if (dx >= 0 && dx < nw && dy >= 0 && dy < nh) {
@@ -667,9 +669,34 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
   }
 }
 
-extern "C" int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, int src_w, int src_row_bytes, void* dst_chw, int H, int W, int new_h,
-                            int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream) {
+// Pure conversion (image already has the network's shape: no resize, no padding): 4 pixels per thread -- 12 source bytes as three
+// aligned 32-bit loads, one 8/16-byte store per colour plane.
+template <typename T>
+__global__ __launch_bounds__(256) void u8hwc_to_chw_kernel(const uint8_t* __restrict__ src, int srow, long src_img, T* __restrict__ dst, int H, int W, int swap_rb) {
+  const int x4 = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x4 * 4 >= W) return;
+  const unsigned* p = reinterpret_cast<const unsigned*>(src + (long)blockIdx.z * src_img + (long)y * srow + x4 * 12);
+  const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+  const unsigned char by[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+  const long plane = (long)H * W;
+  T* d = dst + (long)blockIdx.z * 3 * plane + (long)y * W + x4 * 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int sc = swap_rb ? 2 - c : c;
+    T o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = from_f<T>(__fdiv_rn((float)by[3 * q + sc], 255.f));
+    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(d + c * plane) = *reinterpret_cast<const uint2*>(o);
+    else *reinterpret_cast<uint4*>(d + c * plane) = *reinterpret_cast<const uint4*>(o);
+  }
+}
+
+extern "C" int ey_letterbox_batch(int out_dtype, const uint8_t* src_hwc, int B, int src_h, int src_w, int src_row_bytes, long src_image_bytes, void* dst_chw, int H,
+                                  int W, int new_h, int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream) {
   EY_CHECK(src_hwc && dst_chw, "letterbox: null pointer");
+  EY_CHECK(B > 0 && B <= 65535 && src_image_bytes >= (long)src_h * src_row_bytes, "letterbox: batch of %d images, image pitch %ld bytes", B, src_image_bytes);
   EY_CHECK(out_dtype == EY_F16 || out_dtype == EY_F32, "letterbox: bad dtype");
   EY_CHECK(src_h > 0 && src_w > 0 && src_row_bytes >= 3 * src_w && H > 0 && W > 0, "letterbox: bad extent");
   EY_CHECK(new_h > 0 && new_w > 0 && top >= 0 && left >= 0 && top + new_h <= H && left + new_w <= W, "letterbox: resized image (%dx%d at %d,%d) outside the %dx%d canvas",
@@ -677,13 +704,29 @@ extern "C" int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, in
   EY_CHECK(pad_value >= 0 && pad_value <= 255, "letterbox: pad value");
   // cv::resize: inv_scale = dsize/ssize (double); scale = 1/inv_scale
   const double scale_x = 1.0 / ((double)new_w / (double)src_w), scale_y = 1.0 / ((double)new_h / (double)src_h);
-  dim3 grid((W + 255) / 256, H);
+  if (new_h == src_h && new_w == src_w && H == src_h && W == src_w && W % 4 == 0 && src_row_bytes % 4 == 0 && src_image_bytes % 4 == 0 && ey_aligned(src_hwc, 4) &&
+      ey_aligned(dst_chw, 16)) {
+    dim3 g4((W / 4 + 255) / 256, H, B);
+    if (out_dtype == EY_F16)
+      hipLaunchKernelGGL(u8hwc_to_chw_kernel<f16>, g4, dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (f16*)dst_chw, H, W, swap_rb);
+    else
+      hipLaunchKernelGGL(u8hwc_to_chw_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (float*)dst_chw, H, W, swap_rb);
+    EY_LAUNCH_CHECK("ey_letterbox(convert)");
+    return EY_OK;
+  }
+  dim3 grid((W + 255) / 256, H, B);
   if (out_dtype == EY_F16)
-    hipLaunchKernelGGL(letterbox_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, (f16*)dst_chw, H, W, new_h, new_w, top, left,
-                       pad_value, swap_rb, scale_x, scale_y);
+    hipLaunchKernelGGL(letterbox_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, src_image_bytes, (f16*)dst_chw, H, W, new_h, new_w,
+                       top, left, pad_value, swap_rb, scale_x, scale_y);
   else
-    hipLaunchKernelGGL(letterbox_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, (float*)dst_chw, H, W, new_h, new_w, top, left,
-                       pad_value, swap_rb, scale_x, scale_y);
+    hipLaunchKernelGGL(letterbox_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, src_hwc, src_h, src_w, src_row_bytes, src_image_bytes, (float*)dst_chw, H, W, new_h,
+                       new_w, top, left, pad_value, swap_rb, scale_x, scale_y);
   EY_LAUNCH_CHECK("ey_letterbox");
   return EY_OK;
+}
+
+extern "C" int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, int src_w, int src_row_bytes, void* dst_chw, int H, int W, int new_h,
+                            int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream) {
+  return ey_letterbox_batch(out_dtype, src_hwc, 1, src_h, src_w, src_row_bytes, (long)src_h * src_row_bytes, dst_chw, H, W, new_h, new_w, top, left, pad_value, swap_rb,
+                            stream);
 }

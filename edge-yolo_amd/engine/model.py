@@ -128,11 +128,14 @@ class Model(torch.nn.Module):
 
     def predict_batches(self, batches, stages=4, **kwargs):
         """Throughput form of predict(): a generator over an iterable of BCHW float tensors in [0,1] (all of one shape; host or device,
-        pinned host fp16/fp32 tensors upload fastest) that yields one list of Results per batch, in order.  The layer list is cut into
+        pinned host fp16/fp32 tensors upload fastest) -- or of decoded image batches, uint8 tensors (B,h,w,3) in BGR order like a stack
+        of cv2 images (3 bytes per pixel over PCIe instead of 6; LetterBox to `imgsz` (default 640, minimum rectangle) + BGR->RGB + CHW + /255
+        run on the device in one launch, boxes are scaled back to (h,w) like the reference does for image sources) -- that yields one list of
+        Results per batch, in order.  The layer list is cut into
         `stages` pipeline stages (engine/predictor.py::PipelinedRunner: one hipGraph and one HIP stream per stage; batch i's head/NMS
         run beside batch i+1's neck and batch i+2's backbone), host batches are uploaded on a copy stream under the batches in flight,
         and the detection counts come back through a pinned buffer, so the only host waits are on events.  The results of a batch
-        arrive `stages - 1` submissions later.  Same kwargs as predict() (conf, iou, max_det, half, agnostic_nms, classes, device).
+        arrive `stages` submissions later (one buffer set per stage plus one for the upload in flight).  Same kwargs as predict() (conf, iou, max_det, half, agnostic_nms, classes, device).
         The reference has no counterpart (its stream=True generator still runs one batch at a time)."""
         from .predictor import PipelinedRunner
         from ..utils import ops
@@ -142,9 +145,13 @@ class Model(torch.nn.Module):
             raise TypeError(f"predict_batches() got unsupported arguments {sorted(unknown)}")
         args.update({k: v for k, v in kwargs.items() if k in args})
         pipe, post, pending, nset, dev_ctx = None, None, [], 0, None
+        u8, lb, stage_u8, origs, upload = False, None, None, None, None
         try:
             for x in batches:
                 if pipe is None:
+                    u8 = x.dtype == torch.uint8
+                    if u8 and (x.dim() != 4 or x.shape[3] != 3):
+                        raise ValueError(f"predict_batches: uint8 batches must be (B,h,w,3) image stacks, got {tuple(x.shape)}")
                     device = self._select_device(args["device"] if args["device"] is not None else (x.device if x.is_cuda else None))
                     dev_ctx = torch.cuda.device(device)
                     dev_ctx.__enter__()
@@ -163,36 +170,59 @@ class Model(torch.nn.Module):
                     fns.append(lambda st, last=last: ops.nms_device(last(st)[0][0], args["conf"], args["iou"], args["classes"], args["agnostic_nms"], args["max_det"])[:2])
                     head = m.model[-1]
                     fork, head.head_streams = getattr(head, "head_streams", False), False  # the head is a pipeline stage of its own: no fork inside it
+                    dt = torch.float16 if args["half"] else torch.float32
+                    if u8:
+                        from ..data.augment import LetterBox
+                        stride = int(max(m.stride)) if hasattr(m, "stride") else 32
+                        lb = LetterBox(kwargs.get("imgsz", 640), auto=True, stride=stride)  # as predict() letterboxes a list of same-shape images
+                        example = lb.batch_tensor(x.contiguous().to(device), dt)
+                        u8_shape = tuple(x.shape)
+                    else:
+                        example = post.preprocess(x)
                     try:
-                        pipe = PipelinedRunner(*fns, post.preprocess(x), copy_stream=True)
+                        pipe = PipelinedRunner(*fns, example, copy_stream=True)
                     finally:
                         head.head_streams = fork
-                    nset = pipe.n
+                    nset = pipe.nsets
                     counts = [torch.empty(x.shape[0], dtype=torch.int32).pin_memory() for _ in range(nset)]
                     ready = [torch.cuda.Event() for _ in range(nset)]
-                    dt = torch.float16 if args["half"] else torch.float32
-                if not x.is_cuda and x.dtype != dt:  # a dtype-changing H2D copy would convert on the host: upload as is, convert on the device
+                    if u8:
+                        stage_u8 = [torch.empty(u8_shape, dtype=torch.uint8, device=device) for _ in range(nset)]
+                        origs = [None] * nset
+
+                        def upload(dst, src, j):  # raw bytes over PCIe on the copy stream; ONE conversion launch on the first stage's stream
+                            stage_u8[j].copy_(src, non_blocking=True)
+                            return lambda: lb.batch_tensor(stage_u8[j], dt, out=dst)
+                if u8:
+                    if x.dtype != torch.uint8 or tuple(x.shape) != u8_shape:
+                        raise ValueError(f"predict_batches: every batch must be a uint8 tensor of shape {u8_shape}, got {x.dtype} {tuple(x.shape)}")
+                    x = x.contiguous()
+                elif not x.is_cuda and x.dtype != dt:  # a dtype-changing H2D copy would convert on the host: upload as is, convert on the device
                     x = post.preprocess(x)
                 elif x.dim() != 4 or tuple(x.shape) != tuple(pipe.static_input(0).shape):
                     raise ValueError(f"predict_batches: every batch must have shape {tuple(pipe.static_input(0).shape)}, got {tuple(x.shape)}")
                 while pending and (len(pending) >= nset or pending[0] == pipe.i % nset):  # the buffer set about to be reused must be read first
-                    yield self._finish(pipe, post, pending.pop(0), counts, ready)
-                j = pipe.submit(x)
+                    yield self._finish(pipe, post, pending.pop(0), counts, ready, origs)
+                j = pipe.submit(x, upload=upload)
+                if u8:
+                    origs[j] = x
                 with torch.cuda.stream(pipe.sp):  # counts -> pinned host memory right behind this batch's NMS; the host later waits on the event only
                     counts[j].copy_(pipe.outputs(j)[1], non_blocking=True)
                     ready[j].record(pipe.sp)
                 pending.append(j)
             while pending:
-                yield self._finish(pipe, post, pending.pop(0), counts, ready)
+                yield self._finish(pipe, post, pending.pop(0), counts, ready, origs)
         finally:
             if dev_ctx is not None:
                 dev_ctx.__exit__(None, None, None)
 
     @staticmethod
-    def _finish(pipe, post, j, counts, ready):
+    def _finish(pipe, post, j, counts, ready, origs=None):
         ready[j].synchronize()
         boxes, _ = pipe.outputs(j)
-        post._orig = None
+        # image sources: boxes go back to the original image frame (reference detect/predict.py:36-39); the originals are views of the host batch
+        src = origs[j] if origs is not None else None
+        post._orig = [src[i].numpy() if not src.is_cuda else src[i] for i in range(src.shape[0])] if src is not None else None
         return post.postprocess(boxes, counts[j], pipe.static_input(j), None)
 
 

@@ -84,12 +84,16 @@ class PipelinedRunner:
     def __init__(self, *args, warmup=2, copy_stream=False, streams=None):
         """copy_stream=True: batches handed to submit(x) are copied into the stage-0 input buffer on a stream of their own (host
         tensors: one H2D DMA per batch that overlaps the compute of the batches in flight) instead of on the first stage's stream.
+        A pinned host batch must stay unchanged until its results are out (the usual contract of an asynchronous copy).
         streams: HIP streams to run the stages on (>= one per stage).  HIP binds streams to the 4 hardware queues in creation order,
         so callers that build several pipelines (bench.py's start-up auto-tune) create ONE set of streams and hand it to all of
         them: a second set would alias queues of the first and run ~25 % slower."""
         *stages, example = args
         dev = example.device
         self.dev, self.n = dev, len(stages)
+        # buffer sets: one per stage -- plus one with a copy stream: the upload of batch i is a pipeline stage of its own (it waits for
+        # the batch that used its buffer set before), so with n sets stage 0 idles for the whole transfer of every batch
+        self.nsets = self.n + (1 if copy_stream else 0)
         if streams is not None and len(streams) < len(stages):
             raise ValueError(f"PipelinedRunner: {len(stages)} stages need {len(stages)} streams, got {len(streams)}")
         self.streams = list(streams[: len(stages)]) if streams is not None else [torch.cuda.Stream(device=dev) for _ in stages]
@@ -97,7 +101,7 @@ class PipelinedRunner:
         self.sf, self.sp = self.streams[0], self.streams[-1]
         self.sets = []
         cur = torch.cuda.current_stream(dev)
-        for _ in range(self.n):
+        for _ in range(self.nsets):
             static_in = example.clone()
             self.sf.wait_stream(cur)
             with torch.cuda.stream(self.sf):
@@ -122,23 +126,35 @@ class PipelinedRunner:
             st["post_done"] = st["done"][-1]
 
     def static_input(self, j=None):
-        return self.sets[self.i % self.n if j is None else j]["x"]
+        return self.sets[self.i % self.nsets if j is None else j]["x"]
 
-    def submit(self, x=None):
+    def submit(self, x=None, upload=None):
         """Enqueue one batch (x=None: the batch already sits in static_input()).  Returns the buffer-set index; its outputs
-        are valid after `wait(j)` / a device synchronise."""
-        j = self.i % self.n
+        are valid after `wait(j)` / a device synchronise.  upload(dst, x, j): brings x to the device in place of the plain copy into the
+        stage-0 input buffer `dst` of buffer set j; runs on the copy stream when there is one and may return a callable that is then run
+        on the FIRST STAGE's stream right before its graph (e.g. raw uint8 bytes over PCIe on the copy stream, the conversion kernel
+        on the stage stream: a kernel on the copy stream would make it a fifth compute stream, and HIP's 4 hardware queues then
+        serialise two of the five -- measured 2.9 instead of 1.5 ms per batch)."""
+        j = self.i % self.nsets
         self.i += 1
         st = self.sets[j]
         cur = torch.cuda.current_stream(self.dev)
         self.streams[0].wait_stream(cur)
-        copied = None
+        copied, finish = None, None
         if self.copy_stream is not None and x is not None and x.data_ptr() != st["x"].data_ptr():
             cs = self.copy_stream
             cs.wait_stream(cur)
             cs.wait_event(st["done"][-1])  # every stage of the batch that used this buffer set n submits ago is done (stage 0 read its input long before)
             with torch.cuda.stream(cs):
-                st["x"].copy_(x, non_blocking=True)
+                if upload is not None:
+                    finish = upload(st["x"], x, j)
+                else:
+                    st["x"].copy_(x, non_blocking=True)
+                if x.is_cuda:
+                    # x was allocated on the caller's stream and is read here on the copy stream: without this the caching allocator hands its
+                    # block to the caller's next allocation (e.g. the next batch's converted input) as soon as the caller drops x, while
+                    # this copy may not have run yet -- the batch would silently receive the next batch's pixels
+                    x.record_stream(cs)
                 copied = torch.cuda.Event()
                 copied.record(cs)
             x = None
@@ -148,8 +164,15 @@ class PipelinedRunner:
                 stream.wait_event(st["done"][-1] if s == 0 else st["done"][s - 1])
                 if s == 0 and copied is not None:
                     stream.wait_event(copied)
+                    if finish is not None:
+                        finish()
                 if s == 0 and x is not None and x.data_ptr() != st["x"].data_ptr():
-                    st["x"].copy_(x, non_blocking=True)
+                    if upload is not None:
+                        finish = upload(st["x"], x, j)
+                        if finish is not None:
+                            finish()
+                    else:
+                        st["x"].copy_(x, non_blocking=True)
                 g.replay()
                 st["done"][s].record(stream)
         return j
@@ -159,7 +182,7 @@ class PipelinedRunner:
 
     def wait(self, j=None):
         cur = torch.cuda.current_stream(self.dev)
-        for k in ([j] if j is not None else range(self.n)):
+        for k in ([j] if j is not None else range(self.nsets)):
             cur.wait_event(self.sets[k]["done"][-1])
 
 
@@ -228,15 +251,16 @@ class DetectionPredictor:
         boxes = boxes.clone()
         results = []
         names = self.model.names
-        if self._orig is None:  # tensor source: original image == network input: one clip over the whole batch (4 launches, not 4 per image)
+        # original image == network input (tensor sources; images that already have the network's shape: scale_boxes is gain 1, pad 0):
+        # one clip over the whole batch (4 launches, not 4 per image)
+        same = self._orig is None or all(tuple(o.shape[:2]) == tuple(img.shape[2:]) for o in self._orig)
+        if same:
             ops.clip_boxes(boxes, img.shape[2:])
         for i in range(len(n)):
             det = boxes[i, : n[i]]
-            if self._orig is not None:
-                orig = self._orig[i]
+            orig = self._orig[i] if self._orig is not None else None
+            if not same:
                 det[:, :4] = ops.scale_boxes(img.shape[2:], det[:, :4], orig.shape)
-            else:
-                orig = None
             r = Results(orig, path=f"image{i}.jpg", names=names, boxes=det)
             if orig is None:
                 r.orig_shape = tuple(img.shape[2:])

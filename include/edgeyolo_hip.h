@@ -196,6 +196,12 @@ int ey_nhwc_to_nchw(int dtype, int B, int C, int H, int W, const void* src, int 
  * LetterBox geometry (new size, top/left padding); the resize follows OpenCV's 8-bit fixed-point INTER_LINEAR path. */
 int ey_letterbox(int out_dtype, const uint8_t* src_hwc, int src_h, int src_w, int src_row_bytes, void* dst_chw, int H, int W,
                  int new_h, int new_w, int top, int left, int pad_value, int swap_rb, ey_stream_t stream);
+/* The same for B images of ONE shape in one launch (a decoded batch: image i at src_hwc + i * src_image_bytes -> slot i of the
+ * [B][3][H][W] tensor; one geometry for all).  With new size == source size this is BasePredictor.preprocess alone: uint8 HWC BGR ->
+ * RGB CHW /255 on the device, so a host batch crosses PCIe as 3 bytes per pixel instead of 6 (f16) or 12 (f32). */
+int ey_letterbox_batch(int out_dtype, const uint8_t* src_hwc, int B, int src_h, int src_w, int src_row_bytes, long src_image_bytes,
+                       void* dst_chw, int H, int W, int new_h, int new_w, int top, int left, int pad_value, int swap_rb,
+                       ey_stream_t stream);
 
 /* ---- K8a: linear attention core (LinearAttention.forward, block.py:3360-3373) between the qkv and proj convs.
  * qkv [B,N,3C] channel order [q(h0..)|k|v] (block.py:3364); y [B,N,C]:  k=softmax_d(k); q=softmax_N(q);

@@ -231,7 +231,11 @@ def test_predict_batches_matches_predict():
     import edge_yolo_amd
     torch.manual_seed(11)
     model = edge_yolo_amd.YOLO("yolo11n-test.yaml")
-    xs = [torch.rand(2, 3, 128, 160) for _ in range(6)]
+    # input-sensitive weights and pageable fp32 host batches with half=True: every batch goes through a temporary device tensor that the
+    # copy stream reads after the caller dropped it (regression: without record_stream a batch could receive the next batch's pixels --
+    # invisible with default-initialised weights, whose boxes barely depend on the input)
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    xs = [torch.rand(2, 3, 128, 160) for _ in range(9)]
     outs = list(model.predict_batches(xs, conf=0.25, half=True))
     assert len(outs) == len(xs) and all(len(o) == 2 for o in outs)
     for x, res in zip(xs, outs):
@@ -449,3 +453,26 @@ def test_e2e_predict_surface(E):
         want = onms.non_max_suppression(y[i:i + 1].cpu().numpy(), 0.3, 0.7, max_det=50)[0]
         assert len(a.boxes.data) == len(want) and 0 < len(want) <= 50
         np.testing.assert_allclose(a.boxes.data.cpu().numpy()[:, 4], want[:, 4], atol=2e-2)
+
+
+def test_predict_batches_uint8_image_batches(E):
+    """predict_batches on decoded image batches (uint8 (B,h,w,3) BGR): raw bytes over PCIe, LetterBox + BGR->RGB + CHW + /255 in ONE
+    device launch (ey_letterbox_batch), boxes scaled back to the image frame.  (a) network-shaped images == the float-tensor path on the
+    converted batch, bit for bit; (b) odd-sized images == predict() on the list of ndarrays (per-image ey_letterbox path)."""
+    model = E.YOLO("yolo11n-test.yaml")
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    g = torch.Generator().manual_seed(11)
+    for h, w in ((128, 160), (120, 150)):
+        batches = [torch.randint(0, 256, (3, h, w, 3), generator=g, dtype=torch.uint8) for _ in range(5)]
+        got = list(model.predict_batches(iter([b.pin_memory() for b in batches]), conf=0.25, iou=0.7, device="cuda:0", imgsz=160))
+        assert len(got) == 5
+        for b, res in zip(batches, got):
+            if (h, w) == (128, 160):
+                x = b.flip(-1).permute(0, 3, 1, 2).float() / 255.0
+                want = model.predict(x, conf=0.25, iou=0.7, device="cuda:0", graph=False)
+            else:
+                want = model.predict([im.numpy() for im in b], conf=0.25, iou=0.7, device="cuda:0", graph=False, imgsz=160)
+            assert len(res) == len(want) == 3
+            for r, wv in zip(res, want):
+                np.testing.assert_array_equal(r.boxes.data.cpu().numpy(), wv.boxes.data.cpu().numpy())
+                assert tuple(r.orig_shape[:2]) == (h, w)
