@@ -88,6 +88,7 @@ SIGNATURES = {
     "ey_nchw_to_nhwc": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "ey_nhwc_to_nchw": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "ey_letterbox": (_i, [_i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ey_copy_linear": (_i, [_vp, _vp, _sz, _vp]),
     "ey_letterbox_batch": (_i, [_i, _vp, _i, _i, _i, _i, C.c_long, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ey_linear_attention": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "ey_softmax_attention": (_i, [_i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp]),

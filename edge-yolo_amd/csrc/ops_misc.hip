@@ -670,27 +670,57 @@ __global__ __launch_bounds__(256) void letterbox_kernel(const uint8_t* __restric
 }
 
 // Pure conversion (image already has the network's shape: no resize, no padding): 4 pixels per thread -- 12 source bytes as three
-// aligned 32-bit loads, one 8/16-byte store per colour plane.
+// aligned 32-bit loads, one 8/16-byte store per colour plane; grid-stride, so that a source in PINNED HOST memory (read over PCIe by
+// the kernel itself) can be walked by a SMALL persistent grid: PCIe needs ~100 KB in flight, not 12 800 workgroups of waves that sit
+// in the CUs' wave slots for microseconds per load and keep every other stream's kernels out (measured: the transfer then serialises
+// with the whole pipeline exactly like a DMA copy does).
 template <typename T>
-__global__ __launch_bounds__(256) void u8hwc_to_chw_kernel(const uint8_t* __restrict__ src, int srow, long src_img, T* __restrict__ dst, int H, int W, int swap_rb) {
-  const int x4 = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x4 * 4 >= W) return;
-  const unsigned* p = reinterpret_cast<const unsigned*>(src + (long)blockIdx.z * src_img + (long)y * srow + x4 * 12);
-  const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
-  const unsigned char by[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
-                                (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
-                                (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
-  const long plane = (long)H * W;
-  T* d = dst + (long)blockIdx.z * 3 * plane + (long)y * W + x4 * 4;
+__global__ __launch_bounds__(256) void u8hwc_to_chw_kernel(const uint8_t* __restrict__ src, int srow, long src_img, T* __restrict__ dst, int B, int H, int W, int swap_rb) {
+  const int W4 = W >> 2;
+  const long total = (long)B * H * W4, plane = (long)H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x4 = (int)(i % W4);
+    const long t = i / W4;
+    const int y = (int)(t % H), b = (int)(t / H);
+    const unsigned* p = reinterpret_cast<const unsigned*>(src + (long)b * src_img + (long)y * srow + x4 * 12);
+    const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+    const unsigned char by[12] = {(unsigned char)w0, (unsigned char)(w0 >> 8), (unsigned char)(w0 >> 16), (unsigned char)(w0 >> 24),
+                                  (unsigned char)w1, (unsigned char)(w1 >> 8), (unsigned char)(w1 >> 16), (unsigned char)(w1 >> 24),
+                                  (unsigned char)w2, (unsigned char)(w2 >> 8), (unsigned char)(w2 >> 16), (unsigned char)(w2 >> 24)};
+    T* d = dst + (long)b * 3 * plane + (long)y * W + x4 * 4;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int sc = swap_rb ? 2 - c : c;
-    T o[4];
+    for (int c = 0; c < 3; ++c) {
+      const int sc = swap_rb ? 2 - c : c;
+      T o[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = from_f<T>(__fdiv_rn((float)by[3 * q + sc], 255.f));
-    if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(d + c * plane) = *reinterpret_cast<const uint2*>(o);
-    else *reinterpret_cast<uint4*>(d + c * plane) = *reinterpret_cast<const uint4*>(o);
+      for (int q = 0; q < 4; ++q) o[q] = from_f<T>(__fdiv_rn((float)by[3 * q + sc], 255.f));
+      if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(d + c * plane) = *reinterpret_cast<const uint2*>(o);
+      else *reinterpret_cast<uint4*>(d + c * plane) = *reinterpret_cast<const uint4*>(o);
+    }
   }
+}
+
+// true when p points into host memory (pinned, mapped): kernels that read it are PCIe-bound and get a small persistent grid
+static bool ey_is_host_ptr(const void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+
+// Linear copy, 16 bytes per thread and iteration, grid-stride (the upload of a pinned host batch as an ordinary kernel).
+__global__ __launch_bounds__(256) void linear_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n16) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int ey_copy_linear(const void* src, void* dst, size_t nbytes, ey_stream_t stream) {
+  EY_CHECK(src && dst && nbytes % 16 == 0 && ey_aligned(src, 16) && ey_aligned(dst, 16), "copy_linear: 16-byte aligned pointers and size");
+  if (!nbytes) return EY_OK;
+  const long n16 = (long)(nbytes / 16);
+  long g = (n16 + 255) / 256;
+  const long cap = ey_is_host_ptr(src) ? 128 : 256L * 16;
+  if (g > cap) g = cap;
+  hipLaunchKernelGGL(linear_copy_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, n16);
+  EY_LAUNCH_CHECK("ey_copy_linear");
+  return EY_OK;
 }
 
 extern "C" int ey_letterbox_batch(int out_dtype, const uint8_t* src_hwc, int B, int src_h, int src_w, int src_row_bytes, long src_image_bytes, void* dst_chw, int H,
@@ -706,11 +736,13 @@ extern "C" int ey_letterbox_batch(int out_dtype, const uint8_t* src_hwc, int B, 
   const double scale_x = 1.0 / ((double)new_w / (double)src_w), scale_y = 1.0 / ((double)new_h / (double)src_h);
   if (new_h == src_h && new_w == src_w && H == src_h && W == src_w && W % 4 == 0 && src_row_bytes % 4 == 0 && src_image_bytes % 4 == 0 && ey_aligned(src_hwc, 4) &&
       ey_aligned(dst_chw, 16)) {
-    dim3 g4((W / 4 + 255) / 256, H, B);
+    long g = ((long)B * H * (W / 4) + 255) / 256;
+    const long cap = ey_is_host_ptr(src_hwc) ? 128 : 256L * 16;
+    if (g > cap) g = cap;
     if (out_dtype == EY_F16)
-      hipLaunchKernelGGL(u8hwc_to_chw_kernel<f16>, g4, dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (f16*)dst_chw, H, W, swap_rb);
+      hipLaunchKernelGGL(u8hwc_to_chw_kernel<f16>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (f16*)dst_chw, B, H, W, swap_rb);
     else
-      hipLaunchKernelGGL(u8hwc_to_chw_kernel<float>, g4, dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (float*)dst_chw, H, W, swap_rb);
+      hipLaunchKernelGGL(u8hwc_to_chw_kernel<float>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src_hwc, src_row_bytes, src_image_bytes, (float*)dst_chw, B, H, W, swap_rb);
     EY_LAUNCH_CHECK("ey_letterbox(convert)");
     return EY_OK;
   }

@@ -68,20 +68,27 @@ class LetterBox:
                 L.check(L.lib().ey_letterbox(code, t.data_ptr(), h, w, 3 * w, out[i].data_ptr(), H, W, nh, nw, top, left, 114, int(swap_rb), L.stream()), "ey_letterbox")
         return out
 
-    def batch_tensor(self, images, dtype, swap_rb=True, out=None):
-        """A decoded batch in ONE launch: images = device uint8 tensor (B,h,w,3) (BGR like cv2), contiguous -> (B,3,H,W) `dtype` in [0,1]
-        (LetterBox of every image with one geometry + the reference's preprocess, engine/predictor.py:123-133).  out: write there."""
-        if not (torch.is_tensor(images) and images.is_cuda and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
+    def batch_tensor(self, images, dtype, swap_rb=True, out=None, device=None):
+        """A decoded batch in ONE launch: images = uint8 tensor (B,h,w,3) (BGR like cv2), contiguous -> (B,3,H,W) `dtype` in [0,1]
+        (LetterBox of every image with one geometry + the reference's preprocess, engine/predictor.py:123-133).  out: write there.
+        images may live in PINNED HOST memory: the kernel then reads the bytes over PCIe itself (pinned memory is mapped into the
+        device's address space) -- an ordinary kernel in the caller's stream, which, unlike an H2D copy, runs beside kernels of other
+        streams (measured on this stack: a hipMemcpyAsync H2D does not overlap with kernels of another stream)."""
+        host = torch.is_tensor(images) and not images.is_cuda and images.is_pinned()
+        if not (torch.is_tensor(images) and (images.is_cuda or host) and images.dtype == torch.uint8 and images.dim() == 4 and images.shape[3] == 3
                 and images.is_contiguous()):
-            raise ValueError("LetterBox.batch_tensor: expected a contiguous device uint8 tensor of shape (B,h,w,3)")
+            raise ValueError("LetterBox.batch_tensor: expected a contiguous uint8 tensor of shape (B,h,w,3), on the device or in pinned host memory")
+        if host and (out is None and device is None):
+            raise ValueError("LetterBox.batch_tensor: a pinned host batch needs `out` or `device`")
+        dev = images.device if images.is_cuda else (out.device if out is not None else torch.device(device))
         B, h, w, _ = images.shape
         (nw, nh), top, bottom, left, right, _ = self.geometry((h, w))
         H, W = nh + top + bottom, nw + left + right
         if out is None:
-            out = torch.empty((B, 3, H, W), dtype=dtype, device=images.device)
-        elif tuple(out.shape) != (B, 3, H, W) or out.dtype != dtype or not out.is_contiguous() or out.device != images.device:
-            raise ValueError(f"LetterBox.batch_tensor: out must be a contiguous {dtype} tensor of shape {(B, 3, H, W)} on {images.device}")
-        with torch.cuda.device(images.device):
+            out = torch.empty((B, 3, H, W), dtype=dtype, device=dev)
+        elif tuple(out.shape) != (B, 3, H, W) or out.dtype != dtype or not out.is_contiguous() or out.device != dev:
+            raise ValueError(f"LetterBox.batch_tensor: out must be a contiguous {dtype} tensor of shape {(B, 3, H, W)} on {dev}")
+        with torch.cuda.device(dev):
             L.check(L.lib().ey_letterbox_batch(L.dtype_code(dtype), images.data_ptr(), B, h, w, 3 * w, 3 * w * h, out.data_ptr(), H, W, nh, nw, top, left, 114,
                                                int(swap_rb), L.stream()), "ey_letterbox_batch")
         return out

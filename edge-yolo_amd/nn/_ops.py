@@ -568,6 +568,18 @@ def head_decode_levels(levels, pred, nms=None, xyxy=False):
                    pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")
 
 
+def copy_bytes(dst, src):
+    """dst (device, contiguous) <- src (contiguous; device or PINNED HOST memory, which the device reads over PCIe itself) with a plain
+    copy kernel in the current stream: unlike an H2D hipMemcpyAsync it runs beside kernels of other streams (engine/model.py)."""
+    L.require_device(dst, "copy_bytes")
+    n = dst.numel() * dst.element_size()
+    if not (dst.is_contiguous() and src.is_contiguous() and src.numel() * src.element_size() == n and n % 16 == 0 and (src.is_cuda or src.is_pinned())
+            and dst.data_ptr() % 16 == 0 and src.data_ptr() % 16 == 0):
+        raise ValueError("copy_bytes: contiguous 16-byte aligned tensors of equal byte size (source on the device or in pinned host memory)")
+    L.check(L.lib().ey_copy_linear(src.data_ptr(), dst.data_ptr(), n, L.stream()), "ey_copy_linear")
+    return dst
+
+
 def e2e_topk(pred, k, want_index=False):
     """Detect.postprocess (reference head.py:167-189): pred fp32 (B,4+nc,A) with x1y1x2y2 rows -> (B,k,6) fp32 rows
     [x1,y1,x2,y2,score,class], the k best (anchor, class) pairs per image in descending score order."""

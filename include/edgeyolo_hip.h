@@ -203,6 +203,11 @@ int ey_letterbox_batch(int out_dtype, const uint8_t* src_hwc, int B, int src_h, 
                        void* dst_chw, int H, int W, int new_h, int new_w, int top, int left, int pad_value, int swap_rb,
                        ey_stream_t stream);
 
+/* Linear copy as an ordinary kernel in `stream`: dst (device) <- src (device, or PINNED HOST memory that the device reads over PCIe
+ * itself; a small persistent grid then).  The upload path of `YOLO.predict_batches`: on this stack an H2D hipMemcpyAsync does not
+ * overlap with kernels of other streams, a kernel does.  nbytes and both pointers 16-byte aligned. */
+int ey_copy_linear(const void* src, void* dst, size_t nbytes, ey_stream_t stream);
+
 /* ---- K8a: linear attention core (LinearAttention.forward, block.py:3360-3373) between the qkv and proj convs.
  * qkv [B,N,3C] channel order [q(h0..)|k|v] (block.py:3364); y [B,N,C]:  k=softmax_d(k); q=softmax_N(q);
  * ctx_h = k_h^T v_h; y_h = q_h ctx_h.  head_dim = C/heads <= 64. */
