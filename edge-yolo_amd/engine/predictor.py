@@ -81,7 +81,7 @@ class PipelinedRunner:
     PipelinedRunner(f1, f2, ..., example): stage functions chained (stage k gets stage k-1's return value), example = input batch.
     """
 
-    def __init__(self, *args, warmup=2, copy_stream=False, streams=None):
+    def __init__(self, *args, warmup=2, copy_stream=False, streams=None, extra_sets=None):
         """copy_stream=True: batches handed to submit(x) are copied into the stage-0 input buffer on a stream of their own (host
         tensors: one H2D DMA per batch that overlaps the compute of the batches in flight) instead of on the first stage's stream.
         A pinned host batch must stay unchanged until its results are out (the usual contract of an asynchronous copy).
@@ -93,7 +93,7 @@ class PipelinedRunner:
         self.dev, self.n = dev, len(stages)
         # buffer sets: one per stage -- plus one with a copy stream: the upload of batch i is a pipeline stage of its own (it waits for
         # the batch that used its buffer set before), so with n sets stage 0 idles for the whole transfer of every batch
-        self.nsets = self.n + (1 if copy_stream else 0)
+        self.nsets = self.n + ((1 if copy_stream else 0) if extra_sets is None else int(extra_sets))
         if streams is not None and len(streams) < len(stages):
             raise ValueError(f"PipelinedRunner: {len(stages)} stages need {len(stages)} streams, got {len(streams)}")
         self.streams = list(streams[: len(stages)]) if streams is not None else [torch.cuda.Stream(device=dev) for _ in stages]
