@@ -112,6 +112,9 @@ class Model(torch.nn.Module):
         device = self._select_device(args["device"] if args["device"] is not None else (source.device if isinstance(source, torch.Tensor) and source.is_cuda else None))
         key = tuple((k, str(v)) for k, v in sorted(args.items())) + (("dev", str(device)),)
         if self.predictor is None or self._pred_key != key:
+            if self.predictor is not None:  # options changed: release the old predictor's graphs before anything new is captured
+                self.predictor.close()
+                self.predictor = None
             # AutoBackend order (reference nn/autobackend.py:144-155): to(device) -> fuse() -> half()/float()
             m = self.model.to(device)
             m.fuse()

@@ -7,6 +7,8 @@ stream and, for a fixed (batch, H, W, dtype), captured ONCE into a hipGraph and 
 ~300 ATen ops from Python per batch).  NMS results come back as one fixed-size (B,max_det,6)+(B,) device buffer,
 so there is exactly one D2H copy per batch.
 """
+import contextlib
+import gc
 import threading
 import time
 
@@ -37,6 +39,22 @@ class Profile:
         return time.perf_counter()
 
 
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with Python's cyclic garbage collector held off for the duration: a collection that runs in the middle
+    of a capture may finalise an unrelated captured graph (a replaced predictor, an exhausted pipeline), and destroying a hipGraph while
+    any stream is capturing is an error ("operation not permitted when stream is capturing") that kills the process."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class GraphRunner:
     """Captures `fn(static_input) -> tuple of tensors` into a HIP graph per input signature and replays it."""
 
@@ -56,7 +74,7 @@ class GraphRunner:
             torch.cuda.current_stream(x.device).wait_stream(s)
             torch.cuda.synchronize(x.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 out = self.fn(static_in)
             g = self.graphs[key] = (graph, static_in, out)
         graph, static_in, out = g
@@ -118,7 +136,7 @@ class PipelinedRunner:
             graphs, v = [], static_in
             for f in stages:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with _capture(g):
                     v = f(v)
                 graphs.append(g)
             self.sets.append(dict(x=static_in, graphs=graphs, out=v, done=[torch.cuda.Event() for _ in stages]))
@@ -204,6 +222,11 @@ class DetectionPredictor:
         self.conf, self.iou, self.max_det, self.agnostic_nms, self.classes = conf, iou, max_det, agnostic_nms, classes
         self._lock = threading.Lock()
         self.runner = GraphRunner(self._device_step) if graph else self._device_step
+
+    def close(self):
+        """Drop the captured graphs now (the runner and this predictor reference each other: without this they live until the cyclic
+        collector runs, possibly in the middle of somebody's capture)."""
+        self.runner = None
 
     # ---- device side (captured)
     def _device_step(self, im):

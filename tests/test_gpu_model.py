@@ -476,3 +476,20 @@ def test_predict_batches_uint8_image_batches(E):
             for r, wv in zip(res, want):
                 np.testing.assert_array_equal(r.boxes.data.cpu().numpy(), wv.boxes.data.cpu().numpy())
                 assert tuple(r.orig_shape[:2]) == (h, w)
+
+
+def test_predict_option_changes_rebuild_cleanly(E):
+    """Changing predict() options replaces the predictor (and its captured graph); alternating graph / eager / other thresholds, with a
+    pipeline generator in between, must neither crash (a graph finalised during another capture) nor change results."""
+    model = E.YOLO("yolo11n-test.yaml")
+    model.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in model.model.state_dict().items()}))
+    x = synth.synth_images(2, 128, 160, seed=5)
+    ref = [r.boxes.data.cpu() for r in model.predict(x, conf=0.25, half=True, graph=False)]
+    for k in range(3):
+        a = model.predict(x, conf=0.25, half=True, graph=True)
+        b = model.predict(x, conf=0.25, half=True, graph=False)
+        c = list(model.predict_batches([x, x, x], conf=0.25, half=True))[-1]
+        d = model.predict(x, conf=0.3 + 0.01 * k, half=True, graph=True)
+        for i in range(2):
+            assert torch.equal(a[i].boxes.data.cpu(), ref[i]) and torch.equal(b[i].boxes.data.cpu(), ref[i]) and torch.equal(c[i].boxes.data.cpu(), ref[i])
+            assert len(d[i]) <= len(ref[i])
