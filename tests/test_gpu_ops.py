@@ -116,7 +116,8 @@ def test_wavelet_enhancer(M, dtype, h, w):
     check(to_dev(m, dtype)(xd), om.wavelet_enhancer(sd, "enh", x), dtype)
 
 
-@pytest.mark.parametrize("c,h,w,b", [(16, 160, 160, 2), (32, 80, 80, 3), (64, 40, 40, 2), (128, 20, 20, 3), (64, 21, 37, 2), (16, 6, 4, 1), (32, 50, 34, 2)])
+@pytest.mark.parametrize("c,h,w,b", [(16, 160, 160, 2), (32, 80, 80, 3), (64, 40, 40, 2), (128, 20, 20, 3), (64, 21, 37, 2), (16, 6, 4, 1), (32, 50, 34, 2),
+                                     (128, 22, 30, 2), (128, 6, 10, 1), (128, 40, 40, 1)])
 def test_wavelet_z_kernel_vs_oracle_and_unfused(M, c, h, w, b):
     """ey_wavelet_z (f16: Haar DWT + f_ll / f_h sub-band convs + the Z contraction in ONE kernel) at the network's real (c, map) pairs,
     odd maps and tiles that overhang the map: against the fp32 oracle enhancer (f16 tolerance) and against the three-launch f16 form
