@@ -279,9 +279,7 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
         if (cok) w.load(s_wdw + (ky * K + kx) * C + cb);
         else w.zero();
 #pragma unroll
-        for (int q = 0; q < P; ++q)
-#pragma unroll
-          for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xr[q + kx].get(i), w.get(i), acc[q][i]);
+        for (int q = 0; q < P; ++q) ey_fma8_mix(xr[q + kx], w, acc[q]);
       }
     };
     if constexpr (K * NX <= 16) {

@@ -340,9 +340,7 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(int B, int H, int W,
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-      for (int q = 0; q < P; ++q)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[q][i] = __builtin_fmaf(xin[ky][q + kx].get(i), wv[ky * 3 + kx].get(i), acc[q][i]);
+      for (int q = 0; q < P; ++q) ey_fma8_mix(xin[ky][q + kx], wv[ky * 3 + kx], acc[q]);
   T* yp = y + (long)((b * H + oy) * W + x0) * yCs + c8;
 #pragma unroll
   for (int q = 0; q < P; ++q) {
