@@ -107,11 +107,30 @@ template <> struct BufLoad8<float> {
     v.hi = __builtin_bit_cast(f32x4, b);
   }
 };
+// The activation of N values with the (wave-uniform) selector tested ONCE: with ey_act() inside an unrolled loop the compiler keeps
+// the scalar compare/branch chain per element, which also keeps the exp / rcp latencies of neighbouring elements from overlapping
+// (measured: conv kernels 3-8 % faster with the SiLU loop on its own).
+template <int N>
+__device__ __forceinline__ void ey_act_n(float (&v)[N], int act);
+
 __device__ __forceinline__ float ey_act(float x, int act) {
   switch (act) {
     case EY_ACT_SILU: return x * ey_sigmoid(x);
     case EY_ACT_RELU: return fmaxf(x, 0.f);
     case EY_ACT_SIGMOID: return ey_sigmoid(x);
     default: return x;
+  }
+}
+template <int N>
+__device__ __forceinline__ void ey_act_n(float (&v)[N], int act) {
+  if (act == EY_ACT_SILU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] * ey_sigmoid(v[i]);
+  } else if (act == EY_ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = fmaxf(v[i], 0.f);
+  } else if (act == EY_ACT_SIGMOID) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = ey_sigmoid(v[i]);
   }
 }

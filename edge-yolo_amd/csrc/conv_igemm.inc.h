@@ -1273,13 +1273,19 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(ConvP p, ChainP q) {
       for (int nt = 0; nt < NT1; ++nt) acc[nt] = mma16(a1[t][nt], cur[t], acc[nt]);
     // mid activations (rounded to f16 like the tensor the unfused form writes) = B fragments of the second GEMM
     Vec8<T> mid[KS2];
+    {
+      float mv[8 * KS2];
 #pragma unroll
-    for (int t = 0; t < KS2; ++t)
+      for (int idx = 0; idx < 8 * KS2; ++idx) mv[idx] = idx < 4 * NT1 ? acc[(idx >> 2) < NT1 ? (idx >> 2) : 0][idx & 3] + b1[idx < 4 * NT1 ? idx : 0] : 0.f;
+      ey_act_n(mv, p.act);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int idx = 8 * t + j;
-        mid[t].set(j, (idx < 4 * NT1 && ch1 + idx < p.Cout) ? ey_act(acc[idx >> 2][idx & 3] + b1[idx], p.act) : 0.f);
-      }
+      for (int t = 0; t < KS2; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int idx = 8 * t + j;
+          mid[t].set(j, (idx < 4 * NT1 && ch1 + idx < p.Cout) ? mv[idx] : 0.f);
+        }
+    }
     f32x4 acc2[NT2];
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) acc2[nt] = (f32x4)0.f;
@@ -1295,7 +1301,8 @@ __global__ __launch_bounds__(256) void conv_pw2_kernel(ConvP p, ChainP q) {
         if (ch2 + 4 * nt + 4 <= q.Cout2) {
           float v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = ey_act(acc2[nt][j] + b2[4 * nt + j], q.act2);
+          for (int j = 0; j < 4; ++j) v[j] = acc2[nt][j] + b2[4 * nt + j];
+          ey_act_n(v, q.act2);
           store4(yp + 4 * nt, v);
         } else {  // channel tail (Cout not a multiple of 4, e.g. nc = 10)
 #pragma unroll

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
 #pragma unroll
       for (int i = 0; i < 4 * NT; ++i) {
         const float bb = (p.bias && ch0 + i < p.Cout) ? p.bias[ch0 + i] : 0.f;
-        v[i] = ey_act(v[i] + bb, p.act);
+        v[i] += bb;
       }
+      ey_act_n(v, p.act);
       T* yp = (T*)p.y + m * p.yCs + ch0;
       const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
       if (p.vec_store > 1 && full && sizeof(T) == 2 && NT % 2 == 0) {  // 16-byte accesses (see conv_igemm.hip epilogue)
@@ -301,9 +302,11 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < P; ++q)
+    for (int q = 0; q < P; ++q) {
+      ey_act_n(acc[q], p.dwact);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) bf[ks][q].set(i, cok ? ey_act(acc[q][i], p.dwact) : 0.f);
+      for (int i = 0; i < 8; ++i) bf[ks][q].set(i, cok ? acc[q][i] : 0.f);
+    }
   }
   // ---- pointwise GEMM + epilogue, one pixel block (16 strips' q-th pixel) at a time
   const int ch0 = g * 4 * NT;  // NT == NTpack: lane owns channels ch0 .. ch0 + 4NT of its pixel
@@ -326,7 +329,8 @@ __global__ __launch_bounds__(256) void dsconv_strip_kernel(DsP p) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[4 * nt + j] = ey_act(pacc[nt][j] + bias[4 * nt + j], p.act);
+      for (int j = 0; j < 4; ++j) v[4 * nt + j] = pacc[nt][j] + bias[4 * nt + j];
+    ey_act_n(v, p.act);
     T* yp = (T*)p.y + m * p.yCs + ch0;
     const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
     if (NT % 2 == 0 && p.vec_store > 1 && ch0 + 4 * NT <= p.Cout) {
@@ -476,7 +480,8 @@ __global__ __launch_bounds__(512) void dsconv_tz_kernel(DsP p, const f16* __rest
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[4 * nt + j] = ey_act(pacc[nt][j] + bias[4 * nt + j], p.act);
+        for (int j = 0; j < 4; ++j) v[4 * nt + j] = pacc[nt][j] + bias[4 * nt + j];
+      ey_act_n(v, p.act);
       T* yp = (T*)p.y + m * p.yCs + ch0;
       const T* rp = p.res ? (const T*)p.res + m * p.resCs + ch0 : nullptr;
 #pragma unroll

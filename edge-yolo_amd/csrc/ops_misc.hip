@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(int B, int H, int W, int
     for (int nt = 0; nt < NT; ++nt) {
       const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[nt].v, bq.v, (f32x4)0.f, 0, 0, 0);
       if (ok) {
-        const f16x4 o = {(f16)ey_act(acc[0] + bs[nt][0], act), (f16)ey_act(acc[1] + bs[nt][1], act), (f16)ey_act(acc[2] + bs[nt][2], act),
-                         (f16)ey_act(acc[3] + bs[nt][3], act)};
+        float v4[4] = {acc[0] + bs[nt][0], acc[1] + bs[nt][1], acc[2] + bs[nt][2], acc[3] + bs[nt][3]};
+        ey_act_n(v4, act);
+        const f16x4 o = {(f16)v4[0], (f16)v4[1], (f16)v4[2], (f16)v4[3]};
         *reinterpret_cast<f16x4*>(yp + nt * 16) = o;
       }
     }
@@ -346,8 +347,9 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(int B, int H, int W,
   for (int q = 0; q < P; ++q) {
     if (x0 + q < W) {
       Vec8<T> o;
+      ey_act_n(acc[q], act);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) o.set(i, ey_act(acc[q][i], act));
+      for (int i = 0; i < 8; ++i) o.set(i, acc[q][i]);
       o.store(yp + (long)q * yCs);
     }
   }
