@@ -115,8 +115,10 @@ __global__ __launch_bounds__(256) void dsconv_kernel(DsP p) {
           a0 += bb;
           a1 += bb;
         }
+        float a01[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        ey_act_n(a01, p.dwact);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { d0[i] = from_f<T>(ey_act(a0[i], p.dwact)); d1[i] = from_f<T>(ey_act(a1[i], p.dwact)); }
+        for (int i = 0; i < 4; ++i) { d0[i] = from_f<T>(a01[i]); d1[i] = from_f<T>(a01[4 + i]); }
       }
     }
     __syncthreads();
@@ -456,8 +458,10 @@ __global__ __launch_bounds__(512) void dsconv_tz_kernel(DsP p, const f16* __rest
         acc = ds_mma16(tzf[cc][ky], bfr, acc);
       }
       T* dp = s_dw + r * ROWS + (4 * g) * LSd + c;
+      float dv[4] = {acc[0] + dwb[cc], acc[1] + dwb[cc], acc[2] + dwb[cc], acc[3] + dwb[cc]};
+      ey_act_n(dv, p.dwact);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dp[t * LSd] = (T)ey_act(acc[t] + dwb[cc], p.dwact);
+      for (int t = 0; t < 4; ++t) dp[t * LSd] = (T)dv[t];
     }
     __syncthreads();
     const long cur = tile, nxt = tile + gridDim.x;

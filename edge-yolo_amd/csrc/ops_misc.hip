@@ -293,8 +293,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int B, int H, int W, int C,
     }
   }
   Vec8<T> o;
+  ey_act_n(acc, act);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o.set(i, ey_act(acc[i], act));
+  for (int i = 0; i < 8; ++i) o.set(i, acc[i]);
   o.store(y + m * yCs + c8);
 }
 
