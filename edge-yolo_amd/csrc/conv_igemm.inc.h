@@ -491,6 +491,24 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
             for (int c0 = 0; c0 < Cs; c0 += 128) {
               const int rem = Cs - c0;  // channels left in this source
               Vec8<T> bf[MT][4];
+              if (KS == 1 && rem >= 128) {
+                // 1x1, full 128-channel batch (the common case): no per-k-step tests -- one basic block, so the LDS weight reads of step
+                // k+1 are scheduled under the MFMAs of step k
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                  for (int mt = 0; mt < MT; ++mt) BufLoad8<T>::load(bf[mt][ks], rs[s], voff[mt] + (unsigned)((c0 + ks * 32) * (int)sizeof(T)));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                  Vec8<T> af[NT];
+#pragma unroll
+                  for (int nt = 0; nt < NT; ++nt) af[nt].load(wlane + nt * 16 * p.LSw + kofs + c0 + ks * 32);
+#pragma unroll
+                  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt][ks], acc[mt][nt]);
+                }
+              } else {
 #pragma unroll
               for (int ks = 0; ks < 4; ++ks) {
                 if (ks * 32 < rem) {
@@ -511,6 +529,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(ConvP p) {
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt][ks], acc[mt][nt]);
                 }
+              }
               }
             }
             kofs += Cs;
