@@ -76,8 +76,13 @@ __device__ __forceinline__ void blk_epilogue(const BlkEpi& e, const f32x4 (&acc)
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += ly0 * (lx0 * a00[j] + lx1 * a01[j]) + ly1 * (lx0 * a10[j] + lx1 * a11[j]);
     }
+    if (e.act == EY_ACT_SILU && e.out_scale == 1.f) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (e.act == EY_ACT_SILU && e.out_scale == 1.f) ? v[j] * ey_sigmoid(v[j]) : ey_act(v[j], e.act) * e.out_scale;
+      for (int j = 0; j < 4; ++j) v[j] = v[j] * ey_sigmoid(v[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = ey_act(v[j], e.act) * e.out_scale;
+    }
     if (rp) {
       float rr[4];
       load4(rp + 4 * q, rr);

@@ -235,8 +235,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         if (ch0 + i < p.Cout)
           v[i] += ly0 * (lx0 * to_f(z00[i]) + lx1 * to_f(z01[i])) + ly1 * (lx0 * to_f(z10[i]) + lx1 * to_f(z11[i]));
     }
+    if (p.act == EY_ACT_SILU && p.out_scale == 1.f) {
 #pragma unroll
-    for (int i = 0; i < 4 * NT; ++i) v[i] = (p.act == EY_ACT_SILU && p.out_scale == 1.f) ? v[i] * ey_sigmoid(v[i]) : ey_act(v[i], p.act) * p.out_scale;
+      for (int i = 0; i < 4 * NT; ++i) v[i] = v[i] * ey_sigmoid(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+    }
     T* yp = (T*)p.y + (long)grp * p.yG + m * p.yCs + ch0;
     const T* rp = p.res ? (const T*)p.res + (long)grp * p.yG + m * p.resCs + ch0 : nullptr;
     if (p.vec_store && ch0 + 4 * NT <= p.Cout) {
@@ -1190,8 +1195,13 @@ __global__ __launch_bounds__(256) void conv_pwr_kernel(ConvP p) {
           }
         }
       }
+      if (p.act == EY_ACT_SILU && p.out_scale == 1.f) {
 #pragma unroll
-      for (int i = 0; i < 4 * NT; ++i) v[i] = (p.act == EY_ACT_SILU && p.out_scale == 1.f) ? v[i] * ey_sigmoid(v[i]) : ey_act(v[i], p.act) * p.out_scale;
+        for (int i = 0; i < 4 * NT; ++i) v[i] = v[i] * ey_sigmoid(v[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4 * NT; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+      }
       T* yp = (T*)p.y + (long)m * p.yCs + ch0;
       const T* rp = p.res ? (const T*)p.res + (long)m * p.resCs + ch0 : nullptr;
       if (sizeof(T) == 2 && NT % 2 == 0 && p.vec_store > 1) {
