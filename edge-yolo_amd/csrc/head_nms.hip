@@ -122,17 +122,24 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
   float q = 1.f;
   if (w1) {
     float o = b2[0];
+    // 20 -> hid -> 1 on the VALU: packed fp32 FMAs (v_pk_fma_f32: two lanes of the dot product per instruction, even / odd inputs in the
+    // two halves) -- this file is compiled without FMA contraction for the NMS arithmetic, which had turned every multiply-add of
+    // this loop into a separate v_mul + v_add
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 st2[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) st2[i] = f32x2{stat[2 * i], stat[2 * i + 1]};
 #pragma unroll 4
     for (int j = 0; j < hid; ++j) {
       const f32x4* wr = reinterpret_cast<const f32x4*>(s_w1 + j * 20);
-      float hsum = s_b1[j];
+      f32x2 h2 = {s_b1[j], 0.f};
 #pragma unroll
       for (int i4 = 0; i4 < 5; ++i4) {
         const f32x4 w4 = wr[i4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hsum += w4[i] * stat[i4 * 4 + i];
+        h2 = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, st2[2 * i4], h2);
+        h2 = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, st2[2 * i4 + 1], h2);
       }
-      o += s_w2[j] * fmaxf(hsum, 0.f);
+      o = __builtin_fmaf(s_w2[j], fmaxf(h2[0] + h2[1], 0.f), o);
     }
     q = fminf(fmaxf(ey_sigmoid(o), 1e-6f), 1.f - 1e-6f);
   }
