@@ -4,9 +4,12 @@ GFLv2 head decode -> batched NMS) at 640x640, fp16 storage, synthetic images alr
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--model yolo11n-test.yaml] [--batch 32] [--imgsz 640] [--nc 80]
 
-N>1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; one process per GPU,
-images sharded across ranks (weak scaling: 32 images per GPU), one RCCL all_gather of the padded (B,300,6) result
-rows + counts per `--gather-every` steps.  Rank 0 prints ONE JSON line.
+N>1: one process per GPU, images sharded across ranks (weak scaling: 32 images per GPU), one RCCL all_gather of the padded
+(B,300,6) result rows + counts per `--gather-every` steps.  Rank 0 prints ONE JSON line.  Two launch forms:
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE from the environment), or
+plain `python bench.py --gpus N`: the parent -- which has made no GPU call -- starts N fresh rank processes of this script
+(`self_launch`), relays rank 0's JSON line and exits with the ranks' worst code (the reference launches its own ranks too,
+ultralytics/utils/dist.py:25-67).
 
 A "step" = one batch through the whole device path, replayed from captured hipGraphs: nothing is skipped (NMS and,
 for N>1, the gather are inside the timed region).  `roofline` = per-kernel HIP-event timing of an instrumented eager pass of the
@@ -21,7 +24,10 @@ import argparse
 import contextlib
 import glob
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -56,17 +62,41 @@ def parse(argv=None):
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: exchange the result rows of this many steps with one all_gather")
     ap.add_argument("--force-gather", action="store_true", help="exercise the RCCL gather path on a single GPU (world_size 1)")
     ap.add_argument("--roofline-csv", default="", help="also write roofline.table as CSV (for profiles/)")
+    ap.add_argument("--regime", default="dense", choices=["dense", "sparse"],
+                    help="NMS regime (SURVEY.md §8d): dense = default-init head biases (every slot of max_det fills: the heaviest case, the headline); "
+                         "sparse = Detect.bias_init biases (ultralytics/nn/modules/head.py:150-161), what a trained detector's score surface looks like")
+    ap.add_argument("--cls-bias-shift", type=float, default=0.0, help="--regime sparse: added to the class biases (0 = the reference's bias_init formula)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="test hook: run the launch / barrier / gather / report control flow on the gloo backend with a stub step and NO device work "
+                         "(the JSON line says so; never a measurement)")
     ap.add_argument("--tune", action="append", default=[], metavar="NAME=VALUE",
                     help="developer option: set a dispatch tunable (ey_tune_set, csrc/tune.h) before anything is launched; recorded in the JSON line")
     return ap.parse_args(argv)
 
 
-def build_model(name, dtype, device, seed=0, nc=None):
+def sparse_biases(sd, head_index, nc, strides, cls_shift=0.0):
+    """The `Detect.bias_init` values (ultralytics/nn/modules/head.py:150-161: box 1.0, cls log(5/nc/(640/s)^2); the one2one_* half too
+    when the head has it) written into a state_dict: the SPARSE NMS regime of SURVEY.md §8(d).  cls_shift is added to the class biases
+    (0 = the reference formula; > 0 moves the random-init score surface towards what a trained detector produces at conf 0.25)."""
+    for pre in ("", "one2one_"):
+        for i, s in enumerate(strides):
+            kb, kc = f"model.{head_index}.{pre}cv2.{i}.2.bias", f"model.{head_index}.{pre}cv3.{i}.2.bias"
+            if kb in sd:
+                sd[kb] = torch.ones_like(sd[kb])
+                c = sd[kc].clone()
+                c[:nc] = math.log(5 / nc / (640 / float(s)) ** 2) + cls_shift
+                sd[kc] = c
+    return sd
+
+
+def build_model(name, dtype, device, seed=0, nc=None, regime="dense", cls_shift=0.0):
     import edge_yolo_amd  # noqa: F401
     from edge_yolo_amd.nn.tasks import DetectionModel
     import synthdata as synth  # name-keyed synthetic weights (neutral module shared with the tests; not part of the oracle)
     m = DetectionModel(name, nc=nc)
     sd = synth.synth_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=seed)
+    if regime == "sparse":
+        sparse_biases(sd, len(m.model) - 1, m.model[-1].nc, [float(v) for v in m.stride], cls_shift)
     m.load_state_dict(sd)
     m = m.to(device).fuse()
     m = m.half() if dtype == torch.float16 else m.float()
@@ -194,13 +224,116 @@ def api_throughput(name, sd, nc, batch, imgsz, half, steps, warmup, conf, iou, m
                     f"Results (device boxes + host counts) out; mean detections/img {ndet / max(1, steps * batch):.0f}"}
 
 
-def main():
-    a = parse()
+def self_launch(a, argv):
+    """`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment): start N fresh rank processes of this script, one per
+    GPU, relay rank 0's JSON line, exit with the ranks' worst code.  The parent has imported torch but made NO GPU call and never
+    execs; the ranks are ordinary children (a process that has touched the GPU must not be replaced).  Reference counterpart:
+    ultralytics/utils/dist.py:25-67 (generate_ddp_command: the reference builds and runs its own launch command)."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        # rank 0's stdout is the JSON line; the other ranks' stdout goes to stderr so that exactly one line reaches the caller's stdout
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    line = [ln for ln in (out0 or "").splitlines() if ln.startswith("{")]
+    for ln in (out0 or "").splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    worst = max((abs(c) for c in codes), default=0)
+    if line:
+        print(line[-1], flush=True)
+    elif worst == 0:
+        worst = 1
+    if worst:
+        print(f"bench.py: rank exit codes {codes}" + ("" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
+    return min(worst, 255)
+
+
+def rehearse_cpu(a, world, rank):
+    """--rehearse-cpu: the launch / rendezvous / barrier / gather / report control flow with a stub step on the gloo backend.  Test hook
+    for the self-launcher (tests/test_dist_cpu.py); it performs no device work and its JSON line says so."""
+    from edge_yolo_amd import dist as eydist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, md = a.batch, 300
+    n = [0]
+
+    def step():
+        k = n[0]
+        n[0] += 1
+        boxes = torch.zeros(B, md, 6)
+        count = torch.full((B,), 1, dtype=torch.int32)
+        boxes[:, 0, 0] = torch.arange(B) + (k * world + rank) * B  # row 0, column 0 = global image number
+        return boxes, count
+
+    def reduce_max(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+        return v
+
+    gather = eydist.BoxGatherer(world, B, md, "cpu", own_stream=False, every=a.gather_every) if world > 1 else None
+    seen = []
+    dt, _ = timed_steps(step, lambda: None, gather, a.steps, a.warmup, contextlib.nullcontext, lambda: None,
+                        (dist.barrier if world > 1 else (lambda: None)), reduce_max,
+                        on_block=lambda k: seen.extend(float(r[0, 0]) for r in gather.results(k)))
+    if gather is not None:  # every rank holds every image's rows, in global order (warm-up blocks included)
+        assert seen == [float(v) for v in range((a.warmup + a.steps) * world * B)], seen[:8]
+    if rank == 0:
+        print(json.dumps({"metric": "REHEARSAL (control flow only: gloo backend, stub step, no device work) -- not a measurement", "value": 0.0,
+                          "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+                          "data": "none", "rows_checked": len(seen)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def make_pipeline(model, images, cuts, head_nms, conf, iou, max_det, streams=None, nms_stage=False):
+    """The software pipeline bench.py times: the layer list cut at `cuts`, every stage a captured hipGraph on its own stream; the last
+    model stage (the head) also decodes and runs the NMS, so head + decode + NMS of batch i run beside the backbone / neck of batch
+    i+1.  Every buffer set is pre-filled with `images` (resident batch: no per-step copy).  Shared with the -m gpu tests."""
+    from edge_yolo_amd.engine.predictor import PipelinedRunner
+    from edge_yolo_amd.utils import ops
+    nlayers = len(model.model)
+    post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
+    bounds = [0] + list(cuts) + [nlayers]
+    stages = []
+    for k in range(len(bounds) - 1):
+        lo, hi = bounds[k], bounds[k + 1]
+        if k == 0:
+            stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi, head_nms=head_nms))
+        else:
+            stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi, head_nms=head_nms))
+    if nms_stage:
+        stages.append(post)
+    else:
+        last = stages.pop()
+        stages.append(lambda stt, last=last: post(last(stt)))
+    pipe = PipelinedRunner(*stages, images, streams=streams)
+    for j in range(pipe.nsets):
+        pipe.static_input(j).copy_(images)
+    pipe.cuts = list(cuts)
+    return pipe
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world == 1 and a.gpus > 1:
-        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}, or unset WORLD_SIZE and let bench.py start its own ranks")
+    if a.rehearse_cpu:
+        return rehearse_cpu(a, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_gather = world > 1 or a.force_gather
@@ -218,10 +351,10 @@ def main():
         for kv in a.tune:
             k, v = kv.split("=")
             _lib.check(_lib.lib().ey_tune_set(k.encode(), int(v)), f"--tune {kv}")
-    from edge_yolo_amd.engine.predictor import GraphRunner, PipelinedRunner
+    from edge_yolo_amd.engine.predictor import GraphRunner
     from edge_yolo_amd.utils import ops
     from edge_yolo_amd import dist as eydist
-    model, sd = build_model(a.model, dtype, dev, nc=a.nc)
+    model, sd = build_model(a.model, dtype, dev, nc=a.nc, regime=a.regime, cls_shift=a.cls_bias_shift)
 
     g = torch.Generator(device=dev).manual_seed(rank)
     images = torch.rand(a.batch, 3, a.imgsz, a.imgsz, generator=g, device=dev).to(dtype)  # resident in HBM before timing
@@ -257,30 +390,10 @@ def main():
         # stage s-1 of batch i+1 (every batch still runs every stage in full; the timed region ends with a drain of all stages)
         model.model[-1].head_streams = False  # the head runs as a pipeline stage of its own: no fork inside it (measured: 1.93 -> 1.89 ms)
         nlayers = len(model.model)
-        post = lambda st: ops.nms_device(st[0][0] if isinstance(st[0], (tuple, list)) else st[0], conf, iou, max_det=max_det)[:2]  # noqa: E731
-
         shared_streams = [torch.cuda.Stream(device=dev) for _ in range(5)]  # one set for every candidate pipeline (hardware-queue binding, see PipelinedRunner)
 
         def make_pipe(cuts):
-            bounds = [0] + list(cuts) + [nlayers]
-            stages = []
-            for k in range(len(bounds) - 1):
-                lo, hi = bounds[k], bounds[k + 1]
-                if k == 0:
-                    stages.append(lambda im, lo=lo, hi=hi: model.forward_layers((im, []), lo, hi, head_nms=head_nms))
-                else:
-                    stages.append(lambda stt, lo=lo, hi=hi: model.forward_layers(stt, lo, hi, head_nms=head_nms))
-            # the last model stage (the head) also decodes and runs the NMS: head + decode + NMS of batch i || backbone / neck of batch i+1
-            if a.nms_stage:
-                stages.append(post)
-            else:
-                last = stages.pop()
-                stages.append(lambda stt, last=last: post(last(stt)))
-            pipe = PipelinedRunner(*stages, images, streams=shared_streams)
-            for j in range(pipe.nsets):
-                pipe.static_input(j).copy_(images)  # every buffer set holds the resident batch: no per-step copy
-            pipe.cuts = list(cuts)
-            return pipe
+            return make_pipeline(model, images, cuts, head_nms, conf, iou, max_det, streams=shared_streams, nms_stage=a.nms_stage)
 
         def pipe_fns(pipe):
             def step():
@@ -311,15 +424,17 @@ def main():
         pipe_desc = ("single graph per batch" if a.no_pipeline else
                      f"{len(pipe.cuts) + 1}-stage software pipeline over consecutive batches (layer cuts {pipe.cuts}; last stage = head + decode + NMS), "
                      "one hipGraph and one HIP stream per stage" + (f"; stage count auto-tuned at start-up, trial ms/step {trial_ms}" if trial_ms else ""))
+        regime = ("random-init weights, default head biases (DENSE NMS regime" if a.regime == "dense" else
+                  f"random-init weights + Detect.bias_init head biases{f' + {a.cls_bias_shift:g} on the class biases' if a.cls_bias_shift else ''} (SPARSE NMS regime")
         out = {
             "metric": f"images/sec @ {a.imgsz}x{a.imgsz} {'fp16' if a.dtype == 'f16' else 'fp32'} (EdgeLine-YOLO detection forward path: backbone + DWT neck + GFLv2 head decode + batched NMS)",
             "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",
             "config": {"workload": f"{a.model} (scale n, nc={a.nc}) predict path, {a.imgsz}x{a.imgsz}, batch {a.batch}/GPU, "
-                                   f"conf {conf} iou {iou} max_det {max_det}, random-init weights (dense NMS regime: mean detections/img "
+                                   f"conf {conf} iou {iou} max_det {max_det}, {regime}: mean detections/img "
                                    f"{float(count.float().mean()):.0f})",
-                       "global_batch": a.batch * world, "imgsz": a.imgsz, "nc": a.nc, "pipeline": pipe_desc, **({"tunables": a.tune} if a.tune else {}),
+                       "regime": a.regime, "global_batch": a.batch * world, "imgsz": a.imgsz, "nc": a.nc, "pipeline": pipe_desc, **({"tunables": a.tune} if a.tune else {}),
                        "sharding": f"images x{world}" + (f", RCCL all_gather of boxes every {gather.every} steps" if world > 1 else "")},
         }
     if rank == 0 and not a.no_roofline:

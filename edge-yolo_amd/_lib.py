@@ -109,6 +109,8 @@ SIGNATURES = {
     "ey_nms_candidates": (_i, [_i, _i, _i, _vp, _sz, _f, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "ey_nms_workspace_bytes": (_sz, [_i, _i]),
     "ey_nms_workspace_bytes_ml": (_sz, [_i, _i, _i]),
+    "ey_scale_img": (_i, [_i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "ey_tta_merge": (_i, [_i, _i, _i, _vp, _i, _i, _f, _i, _i, _i, _vp, C.c_long, _i, _vp]),
     "ey_nms": (_i, [_i, _i, _i, _vp, _f, _f, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 

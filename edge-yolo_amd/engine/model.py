@@ -8,6 +8,17 @@ from .predictor import DetectionPredictor
 from ..nn.tasks import DetectionModel, guess_model_task, torch_safe_load_state, yaml_model_load
 
 
+def _plain(o):
+    """YAML dict -> containers torch.load(weights_only=True) accepts (dict / list / str / int / float / bool / None)."""
+    if isinstance(o, dict):
+        return {str(k): _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    if isinstance(o, (str, int, float, bool)) or o is None:
+        return o
+    return str(o)
+
+
 class Model(torch.nn.Module):
     def __init__(self, model="yolo11n.yaml", task=None, verbose=False, nc=None):
         """nc (extension): number of classes for a model built from a YAML (the reference takes it from the dataset YAML at train time,
@@ -67,7 +78,10 @@ class Model(torch.nn.Module):
         (reference AutoBackend does the same, autobackend.py:144-155); the 'fused' flag records which layout the tensors have."""
         m = self.model
         sd = {k: v.detach().float().cpu() if v.is_floating_point() else v.detach().cpu() for k, v in m.state_dict().items()}
-        torch.save({"yaml": m.yaml.get("yaml_file", self.cfg) if isinstance(self.cfg, dict) else self.cfg, "nc": int(m.yaml["nc"]),
+        # a model built from a dict (a custom architecture, or any model that went through _load) is saved WITH that dict: a path string
+        # would only reload where a file of that name exists under cfg/models and still describes the same graph
+        cfg = _plain(m.yaml) if isinstance(self.cfg, dict) else self.cfg
+        torch.save({"yaml": cfg, "nc": int(m.yaml["nc"]),
                     "fused": bool(m.convs_folded()), "state_dict": sd}, filename)
 
     def load(self, weights):
@@ -76,6 +90,11 @@ class Model(torch.nn.Module):
         self.model.load(sd)
         self.predictor = None
         return self
+
+    @property
+    def task_map(self):
+        """task -> {model class, predictor class} (reference engine/model.py:1062-1064, models/yolo/model.py:24-59)."""
+        return {"detect": {"model": DetectionModel, "predictor": DetectionPredictor}}
 
     @property
     def names(self):
@@ -101,16 +120,21 @@ class Model(torch.nn.Module):
         return device
 
     def predict(self, source=None, stream=False, predictor=None, **kwargs):
-        """kwargs (reference cfg/default.yaml:51-65 names): imgsz, half, conf, iou, max_det, agnostic_nms, classes, device."""
+        """kwargs (reference cfg/default.yaml:51-65 names): imgsz, half, conf, iou, max_det, agnostic_nms, classes, device, augment.
+        predictor (reference engine/model.py:505,552: `(predictor or self._smart_load("predictor"))(overrides=...)`): a predictor CLASS to use
+        instead of the task's default; it is constructed with DetectionPredictor's signature (see there) and called with the source."""
         if source is None:
             raise ValueError("predict() needs a source: a BCHW float tensor in [0,1] or HWC uint8 BGR ndarray(s)")
-        args = {"conf": 0.25, "iou": 0.7, "max_det": 300, "half": False, "agnostic_nms": False, "classes": None, "device": None, "graph": True}
+        if predictor is not None and not callable(predictor):
+            raise TypeError(f"predict(predictor=...): expected a predictor class (constructed like DetectionPredictor), got {type(predictor).__name__}")
+        args = {"conf": 0.25, "iou": 0.7, "max_det": 300, "half": False, "agnostic_nms": False, "classes": None, "device": None, "graph": True, "augment": False}
         unknown = set(kwargs) - set(args) - {"imgsz", "verbose", "batch", "save", "mode"}
         if unknown:
             raise TypeError(f"predict() got unsupported arguments {sorted(unknown)}")
         args.update({k: v for k, v in kwargs.items() if k in args})
         device = self._select_device(args["device"] if args["device"] is not None else (source.device if isinstance(source, torch.Tensor) and source.is_cuda else None))
-        key = tuple((k, str(v)) for k, v in sorted(args.items())) + (("dev", str(device)),)
+        pcls = predictor or self.task_map[self.task]["predictor"]
+        key = tuple((k, str(v)) for k, v in sorted(args.items())) + (("dev", str(device)), ("predictor", pcls))
         if self.predictor is None or self._pred_key != key:
             if self.predictor is not None:  # options changed: release the old predictor's graphs before anything new is captured
                 self.predictor.close()
@@ -120,8 +144,8 @@ class Model(torch.nn.Module):
             m.fuse()
             m = m.half() if args["half"] else m.float()
             m.eval()
-            self.predictor = DetectionPredictor(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
-                                                agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=args["graph"])
+            self.predictor = pcls(m, device, half=args["half"], conf=args["conf"], iou=args["iou"], max_det=args["max_det"],
+                                  agnostic_nms=args["agnostic_nms"], classes=args["classes"], graph=args["graph"], augment=args["augment"])
             self._pred_key = key
         self.predictor.imgsz = kwargs.get("imgsz", 640)  # letterbox target for ndarray sources (reference cfg default 640)
         results = self.predictor(source)
@@ -213,10 +237,11 @@ class Model(torch.nn.Module):
                     if x.dtype != torch.uint8 or tuple(x.shape) != u8_shape:
                         raise ValueError(f"predict_batches: every batch must be a uint8 tensor of shape {u8_shape}, got {x.dtype} {tuple(x.shape)}")
                     x = x.contiguous()
-                elif not x.is_cuda and x.dtype != dt:  # a dtype-changing H2D copy would convert on the host: upload as is, convert on the device
-                    x = post.preprocess(x)
-                elif x.dim() != 4 or tuple(x.shape) != tuple(pipe.static_input(0).shape):
-                    raise ValueError(f"predict_batches: every batch must have shape {tuple(pipe.static_input(0).shape)}, got {tuple(x.shape)}")
+                else:
+                    if x.dim() != 4 or tuple(x.shape) != tuple(pipe.static_input(0).shape):  # checked for EVERY float batch, converted or not
+                        raise ValueError(f"predict_batches: every batch must have shape {tuple(pipe.static_input(0).shape)}, got {tuple(x.shape)}")
+                    if not x.is_cuda and x.dtype != dt:  # a dtype-changing H2D copy would convert on the host: upload as is, convert on the device
+                        x = post.preprocess(x)
                 while pending and (len(pending) >= nset or pending[0] == pipe.i % nset):  # the buffer set about to be reused must be read first
                     yield self._finish(pipe, post, pending.pop(0), counts, ready, origs)
                 # float host batches: DMA on a stream of its own (measured faster than the host-reading copy kernel for 6-byte pixels);

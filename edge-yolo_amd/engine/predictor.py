@@ -215,10 +215,18 @@ class PipelinedRunner:
 
 
 class DetectionPredictor:
-    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True, validate_input=False, keep_pred=False):
-        """validate_input=True re-enables the reference's value-range check of tensor sources (data/loaders.py:554-560: max > 1 is an
-        error there); it costs a device reduction and a host sync per call, so it is opt-in."""
-        self.model, self.device, self.half, self.validate_input, self.keep_pred = model, device, half, validate_input, keep_pred
+    def __init__(self, model, device, half=False, conf=0.25, iou=0.7, max_det=300, agnostic_nms=False, classes=None, graph=True, validate_input=None, keep_pred=False,
+                 augment=False):
+        """This signature is the contract for classes injected through `YOLO.predict(predictor=...)` (reference engine/model.py:505,552):
+        the facade constructs `cls(model, device, half=, conf=, iou=, max_det=, agnostic_nms=, classes=, graph=, augment=)` and calls the
+        instance with the source; subclasses usually override `preprocess` / `postprocess` (reference BasePredictor hooks).
+
+        validate_input: the reference's value-range check of tensor sources (LoadTensor._single_check, data/loaders.py:560-566: a tensor
+        whose max exceeds 1 is divided by 255 with a warning).  None (default) = reference behaviour for HOST tensors (the check runs on
+        the host, no device sync) and NO check for DEVICE tensors (it would cost a device reduction + a host sync per call -- a
+        deliberate divergence: a 0..255 device tensor is fed to the network as is); True = check device tensors too; False = never.
+        augment: scale / flip test-time augmentation (DetectionModel._predict_augment; cfg/default.yaml `augment`)."""
+        self.model, self.device, self.half, self.validate_input, self.keep_pred, self.augment = model, device, half, validate_input, keep_pred, bool(augment)
         self.conf, self.iou, self.max_det, self.agnostic_nms, self.classes = conf, iou, max_det, agnostic_nms, classes
         self._lock = threading.Lock()
         self.runner = GraphRunner(self._device_step) if graph else self._device_step
@@ -230,6 +238,10 @@ class DetectionPredictor:
 
     # ---- device side (captured)
     def _device_step(self, im):
+        if self.augment:  # three forwards + descale / clip / concat (reference tasks.py:372-408), then the ordinary NMS on the concatenated anchors
+            pred = self.model(im, augment=True)[0]
+            boxes, count, index = ops.nms_device(pred, self.conf, self.iou, self.classes, self.agnostic_nms, self.max_det)
+            return boxes, count, index, pred
         # the head decode builds the NMS candidates for (conf, classes) in the same pass: the (B,4+nc,A) prediction tensor is only
         # written when the caller asked for it (keep_pred)
         preds = self.model(im, head_nms={"conf": self.conf, "classes": self.classes, "keep_pred": self.keep_pred})
@@ -248,8 +260,13 @@ class DetectionPredictor:
             raise ValueError(f"input tensor should be BCHW with H,W multiples of 32, got {tuple(im.shape)}")
         if not im.is_floating_point():
             raise TypeError("tensor sources must be floating point images in [0,1] (uint8 HWC BGR images go in as numpy arrays)")
-        if self.validate_input and im.numel() and float(im.max()) > 1.0 + 1e-5:
-            raise ValueError("torch.Tensor inputs should be normalized 0.0-1.0")
+        check = (not im.is_cuda) if self.validate_input is None else bool(self.validate_input)
+        if check and im.numel():
+            mx = float(im.max())
+            if mx > 1.0 + float(torch.finfo(im.dtype).eps):  # reference LoadTensor._single_check (data/loaders.py:560-566): warn and rescale
+                import warnings
+                warnings.warn(f"torch.Tensor inputs should be normalized 0.0-1.0 but max value is {mx}. Dividing input by 255.")
+                im = im.float() / 255.0
         im = im.to(self.device, non_blocking=True)
         return (im.half() if self.half else im.float()).contiguous()
 

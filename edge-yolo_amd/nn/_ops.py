@@ -568,6 +568,38 @@ def head_decode_levels(levels, pred, nms=None, xyxy=False):
                    pred.data_ptr(), pred.shape[2], offs, L.stream()), "ey_head_decode_levels")
 
 
+def scale_img(x, ratio, flip_lr=False, gs=32):
+    """scale_img(x.flip(3) if flip_lr else x, ratio, gs=gs) of the reference (utils/torch_utils.py:423-432; ratio 1 and no flip -> x itself)
+    on a contiguous NCHW image batch: one kernel (flip + bilinear resize + 0.447 padding)."""
+    import math
+    L.require_device(x, "scale_img")
+    if ratio == 1.0 and not flip_lr:
+        return x
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    if ratio == 1.0:
+        hs, ws, Hp, Wp = H, W, H, W
+    else:
+        hs, ws = int(H * ratio), int(W * ratio)
+        Hp, Wp = (math.ceil(v * ratio / gs) * gs for v in (H, W))
+    y = torch.empty((B, Cc, Hp, Wp), dtype=x.dtype, device=x.device)
+    with _tr("scale_img_kernel", _nb(x, y), 8.0 * y.numel()):
+        L.check(L.lib().ey_scale_img(L.dtype_code(x.dtype), B, Cc, H, W, x.data_ptr(), hs, ws, Hp, Wp, int(bool(flip_lr)), 0.447, y.data_ptr(), L.stream()), "ey_scale_img")
+    return y
+
+
+def tta_merge(pred, lo, hi, scale, flip, img_hw, out, out_off):
+    """out[:, :, out_off : out_off + hi - lo] = _descale_pred(pred, flip, scale, img_hw)[:, :, lo:hi] (reference tasks.py:388-408)."""
+    L.require_device(pred, "tta_merge")
+    B, no, A = pred.shape
+    if pred.dtype != torch.float32 or out.dtype != torch.float32 or not pred.is_contiguous() or not out.is_contiguous():
+        raise TypeError("tta_merge: contiguous fp32 (B, no, A) tensors")
+    with _tr("tta_merge_kernel", 8 * B * no * (hi - lo)):
+        L.check(L.lib().ey_tta_merge(B, no, A, pred.data_ptr(), lo, hi, float(scale), int(flip or 0), int(img_hw[0]), int(img_hw[1]), out.data_ptr(), out.shape[2],
+                                     out_off, L.stream()), "ey_tta_merge")
+    return out
+
+
 def copy_bytes(dst, src):
     """dst (device, contiguous) <- src (contiguous; device or PINNED HOST memory, which the device reads over PCIe itself) with a plain
     copy kernel in the current stream: unlike an H2D hipMemcpyAsync it runs beside kernels of other streams (engine/model.py)."""

@@ -303,6 +303,10 @@ class Detect(nn.Module):
         for a, b, s in zip(self.cv2, self.cv3, self.stride):
             a[-1].bias.data[:] = 1.0
             b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
+        if self.end2end:  # reference :158-161
+            for a, b, s in zip(self.one2one_cv2, self.one2one_cv3, self.stride):
+                a[-1].bias.data[:] = 1.0
+                b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / float(s)) ** 2)
         self._reset_caches()
 
 

@@ -139,8 +139,18 @@ class BaseModel(nn.Module):
             raise NotImplementedError("profile/visualize/embed hooks are not part of the built path")
         if torch.is_tensor(x) and x.is_cuda and x.device.index != torch.cuda.current_device():
             with torch.cuda.device(x.device):  # launches go to the current device's stream (_lib.stream)
-                return self._predict_once(x, head_nms=head_nms)
-        return self._predict_once(x, head_nms=head_nms)  # augment=True falls back to single scale exactly as the reference does (:181-187)
+                return self._predict_augment(x) if augment else self._predict_once(x, head_nms=head_nms)
+        if augment:  # reference tasks.py:147-148
+            if head_nms is not None:
+                raise ValueError("augment=True returns the concatenated multi-scale predictions; the fused NMS candidate build (head_nms) does not apply")
+            return self._predict_augment(x)
+        return self._predict_once(x, head_nms=head_nms)
+
+    def _predict_augment(self, x):
+        """BaseModel's fallback (reference tasks.py:181-187): models without TTA warn and run single-scale.  DetectionModel overrides."""
+        import warnings
+        warnings.warn(f"{self.__class__.__name__} does not support 'augment=True', reverting to single-scale prediction.")
+        return self._predict_once(x)
 
     def _predict_once(self, x, profile=False, visualize=False, embed=None, head_nms=None):
         return self.forward_layers((x, []), 0, len(self.model), head_nms=head_nms)[0]
@@ -383,6 +393,36 @@ class DetectionModel(BaseModel):
         if mode:
             raise NotImplementedError("edge-yolo_amd builds the inference forward path only")
         return super().train(False)
+
+    def _predict_augment(self, x):
+        """Scale / flip test-time augmentation (reference DetectionModel._predict_augment, tasks.py:372-387): forwards at scales 1, 0.83 and
+        0.67 (the middle one on the left-right mirrored image), `_descale_pred` (:388-397), `_clip_augmented` (:399-408) and the concat over
+        anchors -> ((B, 4+nc, A_total) fp32, None).  Same kernels as the single-scale path, three times, plus ey_scale_img (flip + bilinear
+        resize + 0.447 padding) in front and ey_tta_merge (de-scale, de-flip, clip, concat) behind each forward."""
+        if self.end2end or self.__class__.__name__ != "DetectionModel":  # the reference's own guard (:374-376)
+            return super()._predict_augment(x)
+        from . import _ops
+        img_hw = tuple(x.shape[-2:])
+        gs = int(self.stride.max())
+        nl = self.model[-1].nl
+        g = sum(4 ** k for k in range(nl))
+        scales, flips = (1, 0.83, 0.67), (None, 3, None)
+        preds = []
+        for si, fi in zip(scales, flips):
+            xi = _ops.scale_img(x, float(si), flip_lr=(fi == 3), gs=gs)
+            preds.append(self._predict_once(xi)[0])
+        # _clip_augmented: the first (full-size) output loses its last A//g anchors (its coarsest level), the last (smallest) its first
+        # (A//g)*4^(nl-1) (its finest level); e = 1 excluded level, exactly the reference's index arithmetic
+        spans = [(0, p.shape[-1]) for p in preds]
+        spans[0] = (0, preds[0].shape[-1] - (preds[0].shape[-1] // g) * 1)
+        spans[-1] = ((preds[-1].shape[-1] // g) * 4 ** (nl - 1), preds[-1].shape[-1])
+        total = sum(hi - lo for lo, hi in spans)
+        out = torch.empty((x.shape[0], preds[0].shape[1], total), dtype=torch.float32, device=x.device)
+        off = 0
+        for p, (lo, hi), si, fi in zip(preds, spans, scales, flips):
+            _ops.tta_merge(p, lo, hi, si, fi, img_hw, out, off)
+            off += hi - lo
+        return out, None
 
 
 def torch_safe_load_state(path):

@@ -329,6 +329,18 @@ int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_
            float max_wh, int agnostic, int multi_label, const uint8_t* class_mask, float* out_boxes, int32_t* out_count,
            int32_t* out_index, void* workspace, size_t workspace_bytes, ey_stream_t stream);
 
+/* ---- Test-time augmentation (DetectionModel._predict_augment, nn/tasks.py:372-408; reached by predict(augment=True)).
+ * ey_scale_img = `scale_img(x.flip(3) if flip_lr else x, ratio, gs)` (utils/torch_utils.py:423-432): bilinear resize
+ * (align_corners=False, ATen source-index rule) of the planar NCHW image x [B,C,H,W] to hs x ws = int(H*r) x int(W*r), written into the
+ * top-left corner of y [B,C,Hp,Wp] (Hp,Wp = ceil(H*r/gs)*gs, ...), the rest filled with pad_value (0.447).  x and y must not alias.
+ * ey_tta_merge = `_descale_pred` (:388-397) + the anchor slice `_clip_augmented` (:399-408) keeps + this scale's columns of
+ * `torch.cat(y, -1)`: out[b, r, out_off + a - lo] = f(pred[b, r, a]) for a in [lo, hi), rows 0-3 divided by `scale`, row 0 mirrored
+ * (img_w - x) when flip == 3, row 1 (img_h - y) when flip == 2; flip in {0, 2, 3}.  pred [B,no,A] and out [B,no,A_out] fp32. */
+int ey_scale_img(int dtype, int B, int C, int H, int W, const void* x, int hs, int ws, int Hp, int Wp, int flip_lr, float pad_value, void* y,
+                 ey_stream_t stream);
+int ey_tta_merge(int B, int no, int A, const float* pred, int lo, int hi, float scale, int flip, int img_h, int img_w, float* out, long A_out, int out_off,
+                 ey_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,4 +379,34 @@ class OracleModel:
             y.append(x if L["i"] in self.save else None)
         return x  # (pred, raw)
 
+    @torch.no_grad()
+    def forward_augment(self, x):
+        """DetectionModel._predict_augment (nn/tasks.py:372-408): scales 1 / .83 / .67 (scale_img, utils/torch_utils.py:423-432:
+        bilinear resize to int(h*r) x int(w*r), then 0.447-padding up to ceil(h*r/gs)*gs x ceil(w*r/gs)*gs),
+        lr-flip (dim 3) of the middle one, _descale_pred (:388-397), _clip_augmented (:399-408), concat over anchors.  -> (y, None)."""
+        import math
+        img_h, img_w = x.shape[-2:]
+        gs = int(max(self.stride))
+        ys = []
+        for si, fi in zip((1, 0.83, 0.67), (None, 3, None)):
+            xi = x.flip(fi) if fi else x
+            if si != 1.0:
+                h, w = xi.shape[2:]
+                s = (int(h * si), int(w * si))
+                xi = F.interpolate(xi, size=s, mode="bilinear", align_corners=False)
+                hp, wp = (math.ceil(v * si / gs) * gs for v in (h, w))
+                xi = F.pad(xi, [0, wp - s[1], 0, hp - s[0]], value=0.447)
+            p = self.forward(xi)[0].clone()
+            p[:, :4] /= si
+            if fi == 3:
+                p[:, 0] = img_w - p[:, 0]
+            ys.append(p)
+        nl = len(self.stride)
+        g = sum(4 ** k for k in range(nl))
+        i = (ys[0].shape[-1] // g) * 1
+        ys[0] = ys[0][..., :-i]
+        i = (ys[-1].shape[-1] // g) * 4 ** (nl - 1)
+        ys[-1] = ys[-1][..., i:]
+        return torch.cat(ys, -1), None
+
     __call__ = forward

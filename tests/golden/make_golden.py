@@ -321,7 +321,28 @@ def e2e_case():
     print("e2e", y.shape, [tuple(r.shape) for r in aux["one2one"]], [len(t) for t in det], [len(t) for t in detc], float(y[0, 0, 4]), float(y[0, -1, 4]))
 
 
+def augment_case():
+    """DetectionModel._predict_augment (tasks.py:372-408): scales 1 / 0.83 / 0.67, lr-flip of the middle one, _descale_pred, _clip_augmented,
+    concat over anchors -- `m(x, augment=True)` of the reference on EdgeLine-n at 64x64 and 96x160, plus the predict-time NMS on it."""
+    m, _ = build("yolo11n-test.yaml")
+    m.fuse(verbose=False)
+    out = {}
+    for tag, (b, h, w) in (("64", (2, 64, 64)), ("96x160", (1, 96, 160))):
+        x = synth.synth_images(b, h, w, seed=4)
+        y, none = m(x, augment=True)
+        assert none is None
+        out[f"y_{tag}"] = y.numpy()
+        det = rops.non_max_suppression(y.clone(), 0.25, 0.7, max_det=300, max_time_img=1e6)
+        for i, t in enumerate(det):
+            out[f"det_{tag}_{i}"] = t.numpy()
+        print("augment", tag, tuple(y.shape), [len(t) for t in det])
+    np.savez_compressed(os.path.join(HERE, "augment_n.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--augment-only" in sys.argv:
+        augment_case()
+        sys.exit(0)
     if "--e2e-only" in sys.argv:
         e2e_case()
         sys.exit(0)
@@ -341,6 +362,7 @@ if __name__ == "__main__":
     metrics_cases()
     validator_case()
     e2e_case()
+    augment_case()
     model_small("yolo11n-test.yaml", "edgeline_n_64")
     model_small("yolo11n.yaml", "yolo11n_64")
     for abl in ("GF2Detect", "lineattention", "DSC3K2_Wavelet", "tune"):

@@ -141,3 +141,47 @@ def test_bench_control_flow_gloo_world2():
         for i, r in enumerate(rows):
             assert torch.equal(torch.from_numpy(r), full_b[i, : int(full_c[i])]), f"rank {rank} image {i}"
         assert got[rank][3] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` as typed (no torch.distributed.run around it): the parent starts its own rank processes, relays rank 0's
+# JSON line and exits with the ranks' worst code.  --rehearse-cpu = gloo + stub step (no device work), so this runs without a GPU.
+def _run_bench(*args, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launch_spawns_ranks_and_relays_one_json_line():
+    import json
+    r = _run_bench("--gpus", "2", "--rehearse-cpu", "--steps", "5", "--warmup", "2", "--batch", "3", "--gather-every", "3")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # exactly ONE line on stdout, rank 0's
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["rows_checked"] == (5 + 2) * 2 * 3  # every image of every rank and step reached rank 0, in global order (asserted in the rank)
+    assert "REHEARSAL" in out["metric"]  # the stub can never be mistaken for a measurement
+
+
+def test_bench_self_launch_reports_rank_failure():
+    """Without GPUs the real path must fail in the ranks (no CPU fallback) -- and the launcher must turn that into a non-zero exit
+    code and no JSON line, not into a hang or a silent success."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a host without GPUs")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-roofline", "--no-cpu-baseline", "--no-api")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "rank exit codes" in r.stderr
+
+
+def test_bench_rejects_mismatched_world_size():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

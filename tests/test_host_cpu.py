@@ -255,3 +255,74 @@ def test_e2e_detect_structure_matches_reference(golden_dir):
     for k, v in json.loads(str(g["state_shapes"])).items():
         assert tuple(sd[k].shape) == tuple(v), k
     assert [float(s) for s in m.stride] == [float(s) for s in g["stride"]]
+
+
+def test_custom_architecture_survives_save_reload_save(tmp_path):
+    """a model built from a YAML *dict* (custom architecture whose 'yaml_file' names no shipped file) must round-trip through
+    save() twice: the checkpoint carries the dict itself, not a path that may not exist where it is loaded."""
+    from edge_yolo_amd.nn.tasks import yaml_model_load
+    d = dict(yaml_model_load("yolo11n-test.yaml"))
+    d["yaml_file"] = "/somewhere/else/my-custom-n.yaml"  # a path on the training machine (tools/export_reference_weights.py writes such dicts)
+    d["backbone"] = [list(r) for r in d["backbone"]]
+    d["backbone"][2] = [-1, 2, "DSC3K2_Wavelet", [256, False, 0.5]]  # differs from every shipped YAML (e = 0.5 instead of 0.25)
+    y = edge_yolo_amd.YOLO(d, nc=7)
+    y.model.load_state_dict(synth.synth_state_dict({k: tuple(v.shape) for k, v in y.model.state_dict().items()}))
+    f1, f2 = str(tmp_path / "a.pt"), str(tmp_path / "b.pt")
+    y.save(f1)
+    ck = torch.load(f1, weights_only=True)
+    assert isinstance(ck["yaml"], dict) and ck["yaml"]["backbone"][2][3] == [256, False, 0.5]
+    y1 = edge_yolo_amd.YOLO(f1)
+    y1.save(f2)
+    y2 = edge_yolo_amd.YOLO(f2)
+    a, b = y.model.state_dict(), y2.model.state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert y2.model.model[-1].nc == 7 and [m.type for m in y2.model.model] == [m.type for m in y.model.model]
+
+
+def test_bias_init_covers_the_one2one_branch():
+    """reference head.py:150-161: box biases 1.0, class biases log(5/nc/(640/s)^2), for cv2/cv3 AND (end2end heads) one2one_cv2/one2one_cv3."""
+    import math
+    from edge_yolo_amd.nn.tasks import yaml_model_load
+    d = dict(yaml_model_load("yolo11n-test.yaml"))
+    d["head"] = [list(r) for r in d["head"]]
+    d["head"][-1][2] = "E2EDetect"
+    m = DetectionModel(d)
+    h = m.model[-1]
+    h.bias_init()
+    for towers in ((h.cv2, h.cv3), (h.one2one_cv2, h.one2one_cv3)):
+        for a, b, s in zip(*towers, h.stride):
+            assert torch.all(a[-1].bias == 1.0)
+            assert torch.allclose(b[-1].bias[: h.nc], torch.tensor(math.log(5 / h.nc / (640 / float(s)) ** 2)))
+
+
+def test_bench_sparse_regime_biases_are_bias_init():
+    """bench.py --regime sparse writes exactly Detect.bias_init's values into the synthetic state_dict."""
+    import bench
+    m = DetectionModel("yolo11n-test.yaml")
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    bench.sparse_biases(sd, len(m.model) - 1, m.model[-1].nc, [float(s) for s in m.stride])
+    m.model[-1].bias_init()
+    ref = m.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_host_tensor_range_check_follows_the_reference():
+    """LoadTensor._single_check (data/loaders.py:560-566): a HOST tensor whose max exceeds 1 is divided by 255 with a warning (checked on
+    the host: no device sync); integer tensors are a TypeError; validate_input=False switches the check off."""
+    from edge_yolo_amd.engine.predictor import DetectionPredictor
+
+    class _P(DetectionPredictor):  # preprocess up to the device upload only
+        def __init__(self, validate_input=None):
+            self.validate_input, self.half, self.device = validate_input, False, torch.device("cpu")
+    x = torch.rand(1, 3, 32, 32) * 255
+    with pytest.warns(UserWarning, match="Dividing input by 255"):
+        y = _P().preprocess(x)
+    assert float(y.max()) <= 1.0 and torch.allclose(y, x / 255.0)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(_P().preprocess(x / 255.0), x / 255.0)  # in range: untouched, no warning
+        assert torch.equal(_P(validate_input=False).preprocess(x), x)
+    with pytest.raises(TypeError):
+        _P().preprocess(torch.zeros(1, 3, 32, 32, dtype=torch.uint8))

@@ -216,3 +216,17 @@ def test_e2e_detect(cfg_dir, golden_dir, structure):
     for i in range(2):
         np.testing.assert_array_equal(det[i], g[f"det{i}"])
         np.testing.assert_array_equal(detc[i], g[f"detc{i}"])
+
+
+def test_predict_augment(cfg_dir, golden_dir, structure):
+    """Oracle restatement of DetectionModel._predict_augment (scale/flip TTA, tasks.py:372-408) vs `m(x, augment=True)` of the reference;
+    the predict-time NMS on the concatenated tensor reproduces the reference's rows."""
+    g = _load(golden_dir, "augment_n")
+    o = _oracle(cfg_dir, structure, "yolo11n-test.yaml")
+    for tag, (b, h, w) in (("64", (2, 64, 64)), ("96x160", (1, 96, 160))):
+        y, none = o.forward_augment(synth.synth_images(b, h, w, seed=4))
+        assert none is None and y.shape == g[f"y_{tag}"].shape
+        torch.testing.assert_close(y, g[f"y_{tag}"], rtol=1e-4, atol=1e-4)
+        det = onms.non_max_suppression(g[f"y_{tag}"].numpy(), 0.25, 0.7, max_det=300)
+        for i, d in enumerate(det):
+            np.testing.assert_array_equal(d, g[f"det_{tag}_{i}"].numpy())
