@@ -1,5 +1,6 @@
 // K9+K10 head decode (DGQP quality + DFL expectation + anchor decode + score modulation) and K11 batched NMS.
 #include "common.h"
+#include "tune.h"
 
 // ============================================================================ head decode, one pyramid level
 // thread = one anchor.  64 box logits -> 4 x softmax(16) -> {DFL expectation, top-4 + mean -> FC(20->hid, ReLU)
@@ -268,7 +269,9 @@ extern "C" int ey_head_decode_levels_xyxy(int dtype, int B, int nlevels, const i
 }
 
 static int nms_pow2(int A);
-extern "C" size_t ey_nms_candidates_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4) + (size_t)B * 4 * A * 4; }  // keys + class ids + (cx,cy,w,h)
+static size_t nf_scratch_bytes(int B);
+static size_t nms_cand_bytes(int B, int A) { return ((size_t)B * nms_pow2(A) * (8 + 4) + (size_t)B * 4 * A * 4 + 255) & ~(size_t)255; }  // keys + class ids + (cx,cy,w,h)
+extern "C" size_t ey_nms_candidates_bytes(int B, int A) { return nms_cand_bytes(B, A) + nf_scratch_bytes(B); }  // + the scratch of the NMS fast path
 
 extern "C" int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const int* W, const float* stride, const void* const* box,
                                          const int* box_cstride, const void* const* cls, const int* cls_cstride, int nc, const float* const* q_w1,
@@ -496,7 +499,9 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
                                                                  float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition, int mode,
                                                                  const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                                  float* __restrict__ out_boxes, int* __restrict__ out_count,
-                                                                 int* __restrict__ out_index) {
+                                                                 int* __restrict__ out_index, const int* __restrict__ done, long done_stride) {
+  // behind the fast path (nms_fast.inc.h): only the images it could not complete are redone here, from scratch
+  if (done && done[(long)blockIdx.x * done_stride]) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   NmsShared& S = *reinterpret_cast<NmsShared*>(smem);
   KeptBox* kept = reinterpret_cast<KeptBox*>(smem + sizeof(NmsShared));
@@ -847,7 +852,11 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
 
 static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array length per image (padded for the score kernel grid)
 
-extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return (size_t)B * nms_pow2(A) * (8 + 4); }  // keys + class ids
+#include "nms_fast.inc.h"
+static size_t nf_scratch_bytes(int B) { return (size_t)B * nf_image_bytes(); }
+static size_t nms_keys_bytes(int B, int A) { return ((size_t)B * nms_pow2(A) * (8 + 4) + 255) & ~(size_t)255; }  // keys + class ids
+
+extern "C" size_t ey_nms_workspace_bytes(int B, int A) { return nms_keys_bytes(B, A) + nf_scratch_bytes(B); }  // + the fast path's scratch
 extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size_t)B * (((size_t)A * nc + 255) / 256 * 256) * 8; }
 
 // chunk size of the radix selection: [target, cap] candidates per round.  predict mode needs ~max_det survivors, so small chunks (one key
@@ -855,7 +864,32 @@ extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size
 // A*nc keys with the largest chunk the LDS sort takes.
 static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
                              float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
-                             hipStream_t st, int mode = 0) {
+                             hipStream_t st, int mode = 0, char* fast_scratch = nullptr) {
+  // ---- fast path (predict mode): select K best -> all-pairs bit matrix on the whole chip -> mask-arithmetic resolve; images it cannot
+  // complete (fewer than max_det kept among the K best while more candidates exist) are redone by the general kernel below
+  const int* done = nullptr;
+  long done_stride = 0;
+  const long fast_k = tune().nms_fast_k;
+  if (fast_scratch && fast_k > 0 && !multi_label && mode == 0 && max_det <= 1024 && max_nms >= NF_KMAX) {
+    const int K = (int)(fast_k > NF_KMAX ? NF_KMAX : fast_k);
+    const size_t ib = nf_image_bytes();
+    hipLaunchKernelGGL(nf_select_kernel, dim3(B), dim3(1024), 0, st, nc, A, P, nkeys, boxsrc, img_stride, max_nms, max_wh, agnostic, K, keys, cls_id, fast_scratch, ib);
+    EY_LAUNCH_CHECK("ey_nms(select)");
+    const float lo = (float)((double)iou_thres * (1.0 - 1e-6)), hi = fmaxf((float)((double)iou_thres * (1.0 + 1e-6)), 1e-30f);
+    hipLaunchKernelGGL(nf_mask_kernel, dim3(NF_GROUPS, B), dim3(256), 0, st, iou_thres, lo, hi, fast_scratch, ib);
+    EY_LAUNCH_CHECK("ey_nms(mask)");
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)nf_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NfResShared)) != hipSuccess)
+        return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", sizeof(NfResShared));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(nf_resolve_kernel, dim3(B), dim3(1024), sizeof(NfResShared), st, nc, A, P, boxsrc, img_stride, max_det, max_nms, cls_id, fast_scratch, ib, out_boxes,
+                       out_count, out_index);
+    EY_LAUNCH_CHECK("ey_nms(resolve)");
+    done = &reinterpret_cast<const NfMeta*>(fast_scratch + (size_t)NF_KMAX * 28 + (size_t)NF_TILES * 512)->done;
+    done_stride = (long)(ib / sizeof(int));
+  }
   const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
   // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
   const int partition = !agnostic && nc > 1 && cap == 1024 && !(mode & NMS_MODE_TOPK);
@@ -865,7 +899,7 @@ static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
   hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
-                     target, cap, partition, mode, keys, cls_id, out_boxes, out_count, out_index);
+                     target, cap, partition, mode, keys, cls_id, out_boxes, out_count, out_index, done, done_stride);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }
@@ -898,7 +932,9 @@ static int nms_run(int B, int nc, int A, const float* pred, float conf_thres, fl
       hipLaunchKernelGGL(nms_score_kernel, dim3((unsigned)(P / 256), B), dim3(256), 0, st, nc, A, pred, conf_thres, class_mask, keys, cls_id, (int)P);
   }
   EY_LAUNCH_CHECK("ey_nms(score)");
-  return nms_select_launch(B, nc, A, P, P, multi_label, pred, (long)(4 + nc) * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, st, mode);
+  char* fast = multi_label ? nullptr : (char*)workspace + nms_keys_bytes(B, A);
+  return nms_select_launch(B, nc, A, P, P, multi_label, pred, (long)(4 + nc) * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, st, mode,
+                           fast);
 }
 
 extern "C" int ey_nms(int B, int nc, int A, const float* pred, float conf_thres, float iou_thres, int max_det, int max_nms, float max_wh, int agnostic,
@@ -929,7 +965,7 @@ extern "C" int ey_e2e_topk(int B, int nc, int A, const float* pred_xyxy, int k, 
                  stream, NMS_MODE_XYXY | NMS_MODE_TOPK);
 }
 
-extern "C" int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
+extern "C" int ey_nms_candidates(int B, int nc, int A, void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
                                  int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream) {
   EY_CHECK(candidates && out_boxes && out_count, "nms: null pointer");
   EY_CHECK(B > 0 && nc > 0 && A > 0, "nms: bad extent");
@@ -941,5 +977,6 @@ extern "C" int ey_nms_candidates(int B, int nc, int A, const void* candidates, s
   const int* cls_id = (const int*)(keys + (size_t)B * P);
   const float* box4 = (const float*)(cls_id + (size_t)B * P);
   // only the A real key slots are scanned (the padding up to P is never written by the fused decode)
-  return nms_select_launch(B, nc, A, P, A, 0, box4, 4L * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, (hipStream_t)stream);
+  return nms_select_launch(B, nc, A, P, A, 0, box4, 4L * A, iou_thres, max_det, max_nms, max_wh, agnostic, keys, cls_id, out_boxes, out_count, out_index, (hipStream_t)stream, 0,
+                           (char*)candidates + nms_cand_bytes(B, A));
 }

@@ -631,8 +631,9 @@ def e2e_topk(pred, k, want_index=False):
     return (out, index) if want_index else out
 
 
-def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None, multi_label=False):
-    """pred fp32 (B,4+nc,A) contiguous -> (boxes (B,max_det,6) fp32, count (B,) int32, index (B,max_det) int32)."""
+def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_mask=None, multi_label=False, return_workspace=False):
+    """pred fp32 (B,4+nc,A) contiguous -> (boxes (B,max_det,6) fp32, count (B,) int32, index (B,max_det) int32).
+    return_workspace (tests): also the workspace tensor (keys, class ids, the fast path's per-image scratch with its n_sel / n_total / done words)."""
     L.require_device(pred, "nms")
     if pred.dtype != torch.float32 or not pred.is_contiguous():
         raise ValueError("nms: pred must be a contiguous float32 (B,4+nc,A) tensor")
@@ -648,4 +649,4 @@ def nms(pred, conf_thres, iou_thres, max_det, max_nms, max_wh, agnostic, class_m
         L.check(L.lib().ey_nms(B, no - 4, A, pred.data_ptr(), float(conf_thres), float(iou_thres), int(max_det), int(max_nms), float(max_wh), int(bool(agnostic)), int(bool(multi_label)),
                                class_mask.data_ptr() if class_mask is not None else None, boxes.data_ptr(), count.data_ptr(), index.data_ptr(),
                                ws.data_ptr(), nbytes, L.stream()), "ey_nms")
-    return boxes, count, index
+    return (boxes, count, index, ws) if return_workspace else (boxes, count, index)

@@ -250,8 +250,9 @@ int ey_head_decode_levels_nms(int dtype, int B, int nlevels, const int* H, const
                               const float* const* q_w2, const float* const* q_b2, int q_hidden, float* pred_or_null, int A_total, const int* a_off,
                               float conf_thres, const uint8_t* class_mask, void* candidates, size_t candidates_bytes, ey_stream_t stream);
 /* Second half of ey_nms (selection + greedy suppression, utils/ops.py:277-309 + torchvision.ops.nms) on a candidate buffer
- * written by ey_head_decode_levels_nms.  Outputs as ey_nms. */
-int ey_nms_candidates(int B, int nc, int A, const void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
+ * written by ey_head_decode_levels_nms.  Outputs as ey_nms.  The tail of the buffer (beyond keys / class ids / boxes) is the scratch of
+ * the predict-mode fast path (sorted candidate records + the pairwise suppression bit matrix) and is written by this call. */
+int ey_nms_candidates(int B, int nc, int A, void* candidates, size_t candidates_bytes, float iou_thres, int max_det, int max_nms, float max_wh,
                       int agnostic, float* out_boxes, int32_t* out_count, int32_t* out_index, ey_stream_t stream);
 
 /* ---- End2end (NMS-free) heads: E2EDetect = GF2Detect with end2end=True (head.py:273-298,799-824).

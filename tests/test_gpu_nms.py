@@ -139,3 +139,153 @@ def test_argument_errors(ops):
         ops.non_max_suppression(pred, conf_thres=1.5)
     with pytest.raises(NotImplementedError):
         ops.non_max_suppression(pred, rotated=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The predict-mode fast path (csrc/nms_fast.inc.h: select K best -> all-pairs suppression bit matrix -> mask-arithmetic resolve) and
+# its fallback to the general kernel.  `nms_fast_k` (ey_tune_set) = K; 0 switches the fast path off.
+def _set_fast_k(k):
+    from edge_yolo_amd import _lib
+    _lib.check(_lib.lib().ey_tune_set(b"nms_fast_k", int(k)), "nms_fast_k")
+
+
+def _fast_meta(ws, B, A):
+    """(n_sel, n_total, done) per image from the workspace (layout: nms_fast.inc.h)."""
+    P = (A + 255) // 256 * 256
+    keys_bytes = (B * P * 12 + 255) // 256 * 256
+    img = (2048 * 28 + 528 * 512 + 16 + 255) // 256 * 256
+    raw = ws.cpu().numpy()
+    out = []
+    for b in range(B):
+        off = keys_bytes + b * img + 2048 * 28 + 528 * 512
+        out.append(tuple(int(v) for v in raw[off:off + 12].view(np.int32)))
+    return out
+
+
+def _clustered(rng, B, nc, A, nclusters, sigma, size, lo=0.26, hi=0.99, one_class=False):
+    pred = np.zeros((B, 4 + nc, A), np.float32)
+    for b in range(B):
+        centres = rng.uniform(40, 600, (nclusters, 2))
+        which = rng.integers(0, nclusters, A)
+        pred[b, 0:2] = (centres[which] + rng.normal(0, sigma, (A, 2))).T
+        pred[b, 2:4] = rng.lognormal(np.log(size), 0.25, (2, A))
+        cls = np.zeros(A, np.int64) if one_class else (which * 7 + rng.integers(0, 2, A)) % nc
+        pred[b, 4 + cls, np.arange(A)] = rng.uniform(lo, hi, A)
+    return pred
+
+
+@pytest.mark.parametrize("case", ["dense_one_class", "clustered", "sparse", "agnostic", "small_max_det", "a33600", "few", "classes"])
+def test_fast_path_equals_general_kernel_and_oracle(ops, case):
+    """Rows, counts and anchor indices of the fast path (K = 2048, 1000, 200, 64 -- the small ones force the fallback) == the general
+    kernel alone (K = 0) == the CPU oracle, bit for bit; the workspace's done flags show which path finished each image."""
+    from edge_yolo_amd.nn import _ops
+    rng = np.random.default_rng(31)
+    kw = dict(conf=0.25, iou=0.7, max_det=300, agnostic=False, classes=None)
+    if case == "dense_one_class":  # the random-init model's regime: one dominant class, ~1 of 4 candidates kept, max_det reached deep in the list
+        pred = _clustered(rng, 3, 80, 8400, 400, 6.0, 60.0, one_class=True)
+    elif case == "clustered":
+        pred = _clustered(rng, 2, 40, 6000, 150, 4.0, 50.0)
+        kw["iou"] = 0.6
+    elif case == "sparse":
+        pred = synth.synth_pred(4, 80, 8400, seed=41).numpy()
+    elif case == "agnostic":
+        pred = _clustered(rng, 2, 20, 3000, 80, 5.0, 40.0)
+        kw["agnostic"] = True
+    elif case == "small_max_det":
+        pred = _clustered(rng, 2, 10, 5000, 200, 5.0, 40.0)
+        kw["max_det"] = 17
+    elif case == "a33600":
+        pred = synth.synth_pred(1, 80, 33600, seed=42, dense=True).numpy()
+    elif case == "few":
+        pred = synth.synth_pred(3, 5, 200, seed=43, imgsz=128).numpy()
+        kw["conf"] = 0.05
+    else:
+        pred = synth.synth_pred(2, 80, 8400, seed=44, dense=True).numpy()
+        kw["classes"] = [1, 5, 70]
+    B, no, A = pred.shape
+    want, widx = onms.non_max_suppression(pred, kw["conf"], kw["iou"], max_det=kw["max_det"], agnostic=kw["agnostic"], classes=kw["classes"], return_idx=True)
+    x = torch.tensor(pred).cuda()
+    mask = None
+    if kw["classes"] is not None:
+        mask = torch.zeros(no - 4, dtype=torch.uint8)
+        mask[kw["classes"]] = 1
+        mask = mask.cuda()
+    ref = None
+    try:
+        for K in (0, 2048, 1000, 200, 64):
+            _set_fast_k(K)
+            boxes, count, index, ws = _ops.nms(x, kw["conf"], kw["iou"], kw["max_det"], 30000, 7680.0, kw["agnostic"], mask, False, return_workspace=True)
+            torch.cuda.synchronize()
+            got = (boxes.cpu().numpy(), count.cpu().numpy(), index.cpu().numpy())
+            if ref is None:
+                ref = got
+                for b in range(B):
+                    n = int(got[1][b])
+                    assert n == want[b].shape[0]
+                    np.testing.assert_array_equal(got[2][b, :n], widx[b])
+                    np.testing.assert_array_equal(got[0][b, :n], want[b])
+            else:
+                for a, r in zip(got, ref):
+                    np.testing.assert_array_equal(a, r, err_msg=f"{case}: K={K} differs from the general kernel")
+                meta = _fast_meta(ws, B, A)
+                for b, (nsel, ntot, done) in enumerate(meta):
+                    assert nsel == min(ntot, nsel) and nsel <= K and (nsel == ntot or nsel > 0)
+                    complete = int(got[1][b]) >= kw["max_det"] or nsel == ntot
+                    assert done == int(complete), f"{case}: K={K} image {b}: n_sel={nsel} n_total={ntot} kept={int(got[1][b])} done={done}"
+                if K == 64 and case in ("dense_one_class", "clustered", "a33600"):
+                    assert not all(m[2] for m in meta), f"{case}: K=64 should leave images to the general kernel"
+                if K == 2048 and case in ("sparse", "few", "classes", "small_max_det"):
+                    assert all(m[2] for m in meta), f"{case}: the fast path should finish every image at K=2048 ({meta})"
+    finally:
+        _set_fast_k(2048)
+
+
+def test_fast_path_score_ties_across_the_selection_boundary(ops):
+    """3000 candidates share ONE score (a tie group far larger than K): the threshold select cannot split it, takes only the keys above
+    it, and the general kernel must finish the image; ascending-anchor order inside the tie group is kept."""
+    from edge_yolo_amd.nn import _ops
+    rng = np.random.default_rng(5)
+    A, nc = 4096, 2
+    pred = np.zeros((1, 4 + nc, A), np.float32)
+    pred[0, 0] = rng.uniform(0, 640, A)
+    pred[0, 1] = rng.uniform(0, 640, A)
+    pred[0, 2:4] = 30.0
+    pred[0, 4, :100] = rng.uniform(0.6, 0.9, 100)
+    pred[0, 4, 100:3100] = 0.5
+    pred[0, 5, 3100:] = rng.uniform(0.26, 0.45, A - 3100)
+    want, widx = onms.non_max_suppression(pred, 0.25, 0.5, max_det=300, return_idx=True)
+    try:
+        for K in (2048, 512):
+            _set_fast_k(K)
+            boxes, count, index, ws = _ops.nms(torch.tensor(pred).cuda(), 0.25, 0.5, 300, 30000, 7680.0, False, None, False, return_workspace=True)
+            n = int(count[0])
+            assert n == want[0].shape[0]
+            np.testing.assert_array_equal(index[0, :n].cpu().numpy(), widx[0])
+            np.testing.assert_array_equal(boxes[0, :n].cpu().numpy(), want[0])
+            nsel, ntot, done = _fast_meta(ws, 1, A)[0]
+            assert ntot == A and nsel == 100  # only the keys above the tie group could be selected
+    finally:
+        _set_fast_k(2048)
+
+
+def test_fast_path_iou_decisions_on_the_threshold(ops):
+    """Pairs whose IoU sits within a few ulp of iou_thres: the reciprocal pre-test of iou_gt_fast must hand them to the exact division.
+    400 pairs with the SAME relative geometry (width 64, shift 21: IoU = 43/85 in exact arithmetic) but different heights, so the fp32
+    quotients scatter by rounding over three neighbouring floats; the middle one is the threshold: about half of the partners survive,
+    and which ones is decided in the last bit."""
+    rng = np.random.default_rng(9)
+    n = 400
+    pred = np.zeros((1, 4 + 1, 2 * n), np.float32)
+    for i in range(n):
+        cx, h = 200.0 * i + 100.0, float(np.float32(rng.uniform(20.0, 80.0)))
+        pred[0, :4, 2 * i] = (cx, 100.0, 64.0, h)
+        pred[0, :4, 2 * i + 1] = (cx + 21.0, 100.0, 64.0, h)
+        pred[0, 4, 2 * i] = 0.9 - 1e-4 * i
+        pred[0, 4, 2 * i + 1] = 0.8 - 1e-4 * i
+    thr = float(np.nextafter(np.float32(43.0 / 85.0), np.float32(0)))  # the fp32 quotients take the values float32(43/85) - {0, 1, 2} ulp: the middle one
+    want, widx = onms.non_max_suppression(pred, 0.25, thr, max_det=1024, max_wh=1e6, return_idx=True)
+    boxes, count, index = ops.nms_device(torch.tensor(pred).cuda(), 0.25, thr, max_det=1024, max_wh=1e6)
+    nkept = int(count[0])
+    assert nkept == want[0].shape[0] and n + 100 < nkept < 2 * n - 100, nkept  # a real mix of decisions on both sides of the threshold
+    np.testing.assert_array_equal(index[0, :nkept].cpu().numpy(), widx[0])
+    np.testing.assert_array_equal(boxes[0, :nkept].cpu().numpy(), want[0])
