@@ -495,14 +495,11 @@ __device__ __forceinline__ unsigned long long nms_resolve(unsigned long long mys
   return K;
 }
 
-__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
-                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition, int mode,
-                                                                 const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
-                                                                 float* __restrict__ out_boxes, int* __restrict__ out_count,
-                                                                 int* __restrict__ out_index, const int* __restrict__ done, long done_stride) {
-  // behind the fast path (nms_fast.inc.h): only the images it could not complete are redone here, from scratch
-  if (done && done[(long)blockIdx.x * done_stride]) return;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void nms_general_body(char* smem, int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
+                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition, int mode,
+                                                 const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
+                                                 float* __restrict__ out_boxes, int* __restrict__ out_count,
+                                                 int* __restrict__ out_index) {
   NmsShared& S = *reinterpret_cast<NmsShared*>(smem);
   KeptBox* kept = reinterpret_cast<KeptBox*>(smem + sizeof(NmsShared));
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -850,6 +847,16 @@ __global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, 
     for (int r = tid; r < max_det; r += 1024) out_index[(long)b * max_det + r] = r < nk ? oidx[r] : -1;
 }
 
+__global__ __launch_bounds__(1024) void nms_select_greedy_kernel(int nc, int A, long P, long nkeys, int multi_label, const float* __restrict__ boxsrc, long img_stride,
+                                                                 float iou_thres, int max_det, int max_nms, float max_wh, int agnostic, int target, int cap, int partition, int mode,
+                                                                 const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
+                                                                 float* __restrict__ out_boxes, int* __restrict__ out_count,
+                                                                 int* __restrict__ out_index) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  nms_general_body(smem, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic, target, cap, partition, mode, gkeys, cls_id, out_boxes,
+                   out_count, out_index);
+}
+
 static int nms_pow2(int A) { return (A + 255) / 256 * 256; }  // key array length per image (padded for the score kernel grid)
 
 #include "nms_fast.inc.h"
@@ -865,41 +872,42 @@ extern "C" size_t ey_nms_workspace_bytes_ml(int B, int nc, int A) { return (size
 static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi_label, const float* boxsrc, long img_stride, float iou_thres, int max_det, int max_nms,
                              float max_wh, int agnostic, const unsigned long long* keys, const int* cls_id, float* out_boxes, int32_t* out_count, int32_t* out_index,
                              hipStream_t st, int mode = 0, char* fast_scratch = nullptr) {
-  // ---- fast path (predict mode): select K best -> all-pairs bit matrix on the whole chip -> mask-arithmetic resolve; images it cannot
-  // complete (fewer than max_det kept among the K best while more candidates exist) are redone by the general kernel below
-  const int* done = nullptr;
-  long done_stride = 0;
+  const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
+  // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
+  const int partition = !agnostic && nc > 1 && cap == 1024 && !(mode & NMS_MODE_TOPK);
+  const size_t lds_general = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0) +
+                             (size_t)max_det * 7 * sizeof(float) + 16;
+  EY_CHECK(lds_general + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds_general);
+  // ---- fast path (predict mode): select K best -> all-pairs bit matrix on the whole chip -> mask-arithmetic resolve; an image it cannot
+  // complete (fewer than max_det kept among the K best while more candidates exist) is redone by the general algorithm inside the resolve kernel
   const long fast_k = tune().nms_fast_k;
   if (fast_scratch && fast_k > 0 && !multi_label && mode == 0 && max_det <= 1024 && max_nms >= NF_KMAX) {
     const int K = (int)(fast_k > NF_KMAX ? NF_KMAX : fast_k);
     const size_t ib = nf_image_bytes();
-    hipLaunchKernelGGL(nf_select_kernel, dim3(B), dim3(1024), 0, st, nc, A, P, nkeys, boxsrc, img_stride, max_nms, max_wh, agnostic, K, keys, cls_id, fast_scratch, ib);
+    if (nkeys <= 9 * 1024)  // 640x640: 8400 anchors -> the keys of an image stay in registers (9 per thread)
+      hipLaunchKernelGGL(nf_select_kernel<9>, dim3(B), dim3(1024), 0, st, nc, A, P, nkeys, boxsrc, img_stride, max_nms, max_wh, agnostic, K, keys, cls_id, fast_scratch, ib);
+    else
+      hipLaunchKernelGGL(nf_select_kernel<0>, dim3(B), dim3(1024), 0, st, nc, A, P, nkeys, boxsrc, img_stride, max_nms, max_wh, agnostic, K, keys, cls_id, fast_scratch, ib);
     EY_LAUNCH_CHECK("ey_nms(select)");
-    const float lo = (float)((double)iou_thres * (1.0 - 1e-6)), hi = fmaxf((float)((double)iou_thres * (1.0 + 1e-6)), 1e-30f);
-    hipLaunchKernelGGL(nf_mask_kernel, dim3(NF_GROUPS, B), dim3(256), 0, st, iou_thres, lo, hi, fast_scratch, ib);
+    const float band = iou_thres >= 1e-6f ? (float)((double)iou_thres * 1e-6) : INFINITY;
+    const long mwg = tune().nms_mask_wg > 0 ? tune().nms_mask_wg : NF_MASK_WG;
+    hipLaunchKernelGGL(nf_mask_kernel, dim3((unsigned)mwg, B), dim3(256), 0, st, iou_thres, band, (const float4*)(fast_scratch + (size_t)NF_KMAX * 8),
+                       (const float*)(fast_scratch + (size_t)NF_KMAX * 24), (const NfMeta*)(fast_scratch + (size_t)NF_KMAX * 28 + (size_t)NF_TILES * 512),
+                       (unsigned long long*)(fast_scratch + (size_t)NF_KMAX * 28), ib);
     EY_LAUNCH_CHECK("ey_nms(mask)");
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)nf_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NfResShared)) != hipSuccess)
-        return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", sizeof(NfResShared));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL(nf_resolve_kernel, dim3(B), dim3(1024), sizeof(NfResShared), st, nc, A, P, boxsrc, img_stride, max_det, max_nms, cls_id, fast_scratch, ib, out_boxes,
-                       out_count, out_index);
+    const size_t lds = lds_general > sizeof(NfResShared) ? lds_general : sizeof(NfResShared);
+    if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nf_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
+    hipLaunchKernelGGL(nf_resolve_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic, target, cap, partition,
+                       keys, cls_id, fast_scratch, ib, out_boxes, out_count, out_index);
     EY_LAUNCH_CHECK("ey_nms(resolve)");
-    done = &reinterpret_cast<const NfMeta*>(fast_scratch + (size_t)NF_KMAX * 28 + (size_t)NF_TILES * 512)->done;
-    done_stride = (long)(ib / sizeof(int));
+    return EY_OK;
   }
-  const int cap = (multi_label || max_det > 512) ? NMS_CAP : 1024, target = cap / 2;
-  // per-class NMS with small chunks: the class-partitioned greedy (wave w resolves the classes c % 16 == w without workgroup barriers)
-  const int partition = !agnostic && nc > 1 && cap == 1024 && !(mode & NMS_MODE_TOPK);
-  const size_t lds = sizeof(NmsShared) + (size_t)max_det * sizeof(KeptBox) + (partition ? (size_t)16 * max_det * sizeof(unsigned short) : 0) +
-                     (size_t)max_det * 7 * sizeof(float) + 16;
-  EY_CHECK(lds + 4096 <= 160 * 1024, "nms: max_det=%d needs %zu B of LDS", max_det, lds);
+  const size_t lds = lds_general;
   if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nms_select_greedy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
   hipLaunchKernelGGL(nms_select_greedy_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, multi_label, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic,
-                     target, cap, partition, mode, keys, cls_id, out_boxes, out_count, out_index, done, done_stride);
+                     target, cap, partition, mode, keys, cls_id, out_boxes, out_count, out_index);
   EY_LAUNCH_CHECK("ey_nms(sort_greedy)");
   return EY_OK;
 }

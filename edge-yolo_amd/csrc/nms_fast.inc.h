@@ -21,7 +21,6 @@
 #define NF_KMAX 2048
 #define NF_NB (NF_KMAX / 64)
 #define NF_TILES (NF_NB * (NF_NB + 1) / 2)
-#define NF_GROUPS 144  // sum over cb of ceil((cb+1)/4): (column block, 4 row blocks) work items of nf_mask per image
 
 struct NfMeta { int n_sel, n_total, done, pad; };
 static inline size_t nf_image_bytes() {
@@ -93,15 +92,51 @@ __device__ __forceinline__ void nf_sort2048(unsigned long long& k0, unsigned lon
   }
 }
 
+// Descending bitonic sort of n2 <= 1024 keys (n2 a power of two >= 64), one per thread; threads >= n2 carry zeros through the same
+// steps (their exchanges stay among themselves).  n2 = 64 needs no barrier at all.
+__device__ __forceinline__ unsigned long long nf_sort_n(unsigned long long key, unsigned long long* xch, int n2) {
+  const int t = threadIdx.x;
+#pragma unroll 1
+  for (int k = 2; k <= n2; k <<= 1) {
+    const bool desc = (t & k) == 0;
+#pragma unroll 1
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      unsigned long long other;
+      if (j >= 64) {
+        xch[t] = key;
+        __syncthreads();
+        other = xch[t ^ j];
+        __syncthreads();
+      } else {
+        const unsigned lo = __shfl_xor((unsigned)key, j, 64), hi = __shfl_xor((unsigned)(key >> 32), j, 64);
+        other = ((unsigned long long)hi << 32) | lo;
+      }
+      const bool keep_max = desc == ((t & j) == 0);
+      key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
+    }
+  }
+  return key;
+}
+
 struct NfSelShared {
-  unsigned hist[4096];
-  unsigned long long sel[NF_KMAX];
-  unsigned long long xch[NF_KMAX];
+  unsigned hist[4096];                // counts per score digit, then suffix counts c(d) = #keys with digit >= d
+  unsigned long long sel[NF_KMAX];    // selected keys, grouped by digit (descending), unordered inside a digit
+  unsigned long long xch[NF_KMAX];    // fill counters of the scatter (as unsigned[4096]) / exchange buffer of the bitonic fallback / sorted keys
   unsigned wred[16][3];
-  unsigned vmin, vmax, total;
-  int bsel, cnt;
+  unsigned vmin, vmax, total, maxbin;
+  int bsel;
 };
 
+// KPT > 0: the image's keys live in registers (KPT per thread, nkeys <= 1024 * KPT) and are read from memory once;
+// KPT == 0: any nkeys, every pass re-reads them (L2).
+//
+// Selection and sort share ONE 4096-bin histogram of the score bits over [vmin, vmax] (digit = (v - vmin) >> shift): the suffix counts
+// c(d) give (a) the smallest digit whose keys-and-above fit K -- the selection (whole digits only: a little less than K when the
+// boundary digit is crowded; what is left out is the general kernel's business if it ever matters) -- and (b) every selected key's
+// position up to the order inside its digit: pos = c(d + 1) + (rank among the ~2 keys of digit d).  That replaces the 66-step bitonic
+// sort of 2048 keys by a scatter and a few compares; digits holding more than 64 selected keys (score ties, clustered scores) fall back
+// to the bitonic network.
+template <int KPT>
 __global__ __launch_bounds__(1024) void nf_select_kernel(int nc, int A, long P, long nkeys, const float* __restrict__ boxsrc, long img_stride, int max_nms, float max_wh,
                                                          int agnostic, int K, const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id,
                                                          char* __restrict__ scratch, size_t img_bytes) {
@@ -111,18 +146,33 @@ __global__ __launch_bounds__(1024) void nf_select_kernel(int nc, int A, long P, 
   const float* pb = boxsrc + (long)b * img_stride;
   const int* cid = cls_id + (long)b * P;
   char* img = scratch + (size_t)b * img_bytes;
+  unsigned long long kr[KPT > 0 ? KPT : 1];
+  if constexpr (KPT > 0) {
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+      const long i = tid + 1024L * q;
+      kr[q] = i < nkeys ? keys[i] : 0ull;
+    }
+  }
+  auto for_each_key = [&](auto&& f) {
+    if constexpr (KPT > 0) {
+#pragma unroll
+      for (int q = 0; q < KPT; ++q) f(kr[q]);
+    } else {
+      for (long i = tid; i < nkeys; i += 1024) f(keys[i]);
+    }
+  };
 
   // ---- pass 0: number of candidates, range of their score bits
   unsigned n = 0, vmin = 0xFFFFFFFFu, vmax = 0u;
-  for (long i = tid; i < nkeys; i += 1024) {
-    const unsigned long long k = keys[i];
+  for_each_key([&](unsigned long long k) {
     if (k != 0ull) {
       const unsigned v = (unsigned)(k >> 32);
       ++n;
       vmin = min(vmin, v);
       vmax = max(vmax, v);
     }
-  }
+  });
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     n += __shfl_xor(n, off, 64);
@@ -130,82 +180,94 @@ __global__ __launch_bounds__(1024) void nf_select_kernel(int nc, int A, long P, 
     vmax = max(vmax, (unsigned)__shfl_xor(vmax, off, 64));
   }
   if (lane == 0) { S.wred[wave][0] = n; S.wred[wave][1] = vmin; S.wred[wave][2] = vmax; }
+  for (int i = tid; i < 4096; i += 1024) { S.hist[i] = 0u; reinterpret_cast<unsigned*>(S.xch)[i] = 0u; }
   __syncthreads();
   if (tid == 0) {
     unsigned t = 0, mn = 0xFFFFFFFFu, mx = 0u;
     for (int w = 0; w < 16; ++w) { t += S.wred[w][0]; mn = min(mn, S.wred[w][1]); mx = max(mx, S.wred[w][2]); }
-    S.total = t; S.vmin = mn; S.vmax = mx; S.cnt = 0;
+    S.total = t; S.vmin = mn; S.vmax = mx; S.bsel = 4096; S.maxbin = 0u;
   }
   __syncthreads();
   const unsigned total = S.total;
-  // ---- threshold T on the score bits: keys with v >= T are exactly the best n_sel <= K candidates
-  unsigned T = 0u;  // (every candidate)
-  if (total > (unsigned)K) {
-    unsigned lo_r = S.vmin, hi_r = S.vmax, Q = (unsigned)K;
-    T = hi_r + 1u;  // nothing selected yet (vmax < 0xFFFFFFFF: scores are finite positive floats)
-    while (true) {  // wave-uniform state; at most three rounds for a 32-bit range
-      const unsigned range = hi_r - lo_r;
-      int shift = 0;
-      while ((range >> shift) >= 4096u) ++shift;
-      for (int i = tid; i < 4096; i += 1024) S.hist[i] = 0u;
-      if (tid == 0) S.bsel = 4096;
-      __syncthreads();
-      for (long i = tid; i < nkeys; i += 1024) {
-        const unsigned long long k = keys[i];
-        if (k != 0ull) {
-          const unsigned v = (unsigned)(k >> 32);
-          if (v >= lo_r && v <= hi_r) atomicAdd(&S.hist[(v - lo_r) >> shift], 1u);
-        }
-      }
-      __syncthreads();
-      nms_block_suffix_scan(S.hist);  // hist[d] = #keys of the range with digit >= d
-      {
-        int best = 4096;  // smallest digit whose suffix count fits the quota (counts fall with d: the first hit of a thread is its smallest)
-        for (int d = 4 * tid + 3; d >= 4 * tid; --d)
-          if (S.hist[d] <= Q) best = d;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
-        if (lane == 0 && best < 4096) atomicMin(&S.bsel, best);
-      }
-      __syncthreads();
-      const int bs = S.bsel;
-      const unsigned taken = bs < 4096 ? S.hist[bs] : 0u;
-      __syncthreads();  // (hist is rewritten by the next round)
-      if (bs < 4096) T = lo_r + ((unsigned)bs << shift);
-      Q -= taken;
-      if (bs == 0 || shift == 0 || Q == 0u) break;
-      const unsigned nlo = lo_r + ((unsigned)(bs - 1) << shift);  // the boundary digit: more keys than the quota left
-      hi_r = min(hi_r, nlo + ((1u << shift) - 1u));
-      lo_r = nlo;
-    }
+  if (total == 0u) {  // nothing passed conf: no records, the resolve kernel writes the empty result
+    if (tid == 0) { NfMeta* m = nf_meta(img); m->n_sel = 0; m->n_total = 0; m->done = 0; }
+    return;
   }
-  // ---- gather (unordered) + sort
-  for (long i = tid; i < nkeys; i += 1024) {
-    const unsigned long long k = keys[i];
-    if (k != 0ull && (unsigned)(k >> 32) >= T) {
-      const int p = atomicAdd(&S.cnt, 1);
-      if (p < NF_KMAX) S.sel[p] = k;
-    }
-  }
+  const unsigned lo_r = S.vmin;
+  int shift = 0;
+  while (((S.vmax - lo_r) >> shift) >= 4096u) ++shift;
+  for_each_key([&](unsigned long long k) {
+    if (k != 0ull) atomicAdd(&S.hist[((unsigned)(k >> 32) - lo_r) >> shift], 1u);
+  });
   __syncthreads();
-  const int nsel = min(S.cnt, K);  // (== S.cnt by construction)
-  unsigned long long k0, k1;
-  if (nsel <= 1024) {
-    k0 = nms_sort1024(tid < nsel ? S.sel[tid] : 0ull, S.xch);
+  {
+    unsigned mb = max(max(S.hist[4 * tid], S.hist[4 * tid + 1]), max(S.hist[4 * tid + 2], S.hist[4 * tid + 3]));  // (bins above the selection included: harmless)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mb = max(mb, (unsigned)__shfl_xor(mb, off, 64));
+    if (lane == 0) atomicMax(&S.maxbin, mb);
+  }
+  nms_block_suffix_scan(S.hist);  // hist[d] = c(d) = #keys with digit >= d  (2 barriers inside: maxbin is complete afterwards)
+  int bs = 0;  // first selected digit
+  if (total > (unsigned)K) {
+    int best = 4096;  // smallest digit whose suffix count fits K (counts fall with d: a thread's first hit from above is its smallest)
+    for (int d = 4 * tid + 3; d >= 4 * tid; --d)
+      if (S.hist[d] <= (unsigned)K) best = d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off, 64));
+    if (lane == 0 && best < 4096) atomicMin(&S.bsel, best);
     __syncthreads();
-    S.sel[tid] = k0;
+    bs = S.bsel;
+  }
+  const int nsel = bs < 4096 ? (int)S.hist[bs] : 0;
+  // ---- scatter by digit: pos = c(d + 1) + arrival order inside the digit
+  unsigned* fill = reinterpret_cast<unsigned*>(S.xch);
+  for_each_key([&](unsigned long long k) {
+    if (k != 0ull) {
+      const int d = (int)(((unsigned)(k >> 32) - lo_r) >> shift);
+      if (d >= bs) S.sel[(d < 4095 ? S.hist[d + 1] : 0u) + atomicAdd(&fill[d], 1u)] = k;
+    }
+  });
+  __syncthreads();
+  const bool crowded = S.maxbin > 64u;  // (block-uniform)
+  if (!crowded) {
+    // order inside a digit: rank = number of larger keys among its (few) keys
+    unsigned long long mine[2];
+    int dst[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int e = tid + 1024 * q;
+      dst[q] = -1;
+      if (e < nsel) {
+        const unsigned long long k = S.sel[e];
+        const int d = (int)(((unsigned)(k >> 32) - lo_r) >> shift);
+        const int s0 = d < 4095 ? (int)S.hist[d + 1] : 0, s1 = (int)S.hist[d];
+        int r = 0;
+        for (int x = s0; x < s1; ++x) r += S.sel[x] > k;
+        mine[q] = k;
+        dst[q] = s0 + r;
+      }
+    }
+    __syncthreads();  // (fill[] aliases xch: every scatter counter has been consumed before the sorted keys overwrite it)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (dst[q] >= 0) S.xch[dst[q]] = mine[q];
+  } else if (nsel <= 1024) {
+    int n2 = 64;
+    while (n2 < nsel) n2 <<= 1;
+    const unsigned long long sorted = nf_sort_n(tid < nsel ? S.sel[tid] : 0ull, S.xch, n2);
+    __syncthreads();
+    S.xch[tid] = sorted;
   } else {
-    k0 = 2 * tid < nsel ? S.sel[2 * tid] : 0ull;
-    k1 = 2 * tid + 1 < nsel ? S.sel[2 * tid + 1] : 0ull;
+    unsigned long long k0 = 2 * tid < nsel ? S.sel[2 * tid] : 0ull, k1 = 2 * tid + 1 < nsel ? S.sel[2 * tid + 1] : 0ull;
     __syncthreads();
     nf_sort2048(k0, k1, S.xch);
-    S.sel[2 * tid] = k0;
-    S.sel[2 * tid + 1] = k1;
+    S.xch[2 * tid] = k0;
+    S.xch[2 * tid + 1] = k1;
   }
   __syncthreads();
   // ---- candidate records in score order: key, class-offset box (ops.py:289), area -- the operands of torchvision's nms
   for (int e = tid; e < nsel; e += 1024) {
-    const unsigned long long key = S.sel[e];
+    const unsigned long long key = S.xch[e];
     const int a = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
     const float cx = pb[a], cy = pb[(long)A + a], w = pb[2L * A + a], h = pb[3L * A + a];
     const float hw = __fmul_rn(w, 0.5f), hh = __fmul_rn(h, 0.5f);  // xywh2xyxy, ops.py:430-432
@@ -224,47 +286,108 @@ __global__ __launch_bounds__(1024) void nf_select_kernel(int nc, int A, long P, 
   }
 }
 
-// (column block cb, row blocks 4*grp .. 4*grp+3): one wave per 64 x 64 tile.
-__global__ __launch_bounds__(256) void nf_mask_kernel(float thr, float thr_lo, float thr_hi, char* __restrict__ scratch, size_t img_bytes) {
-  __shared__ KeptBox rows[4][64];
-  char* img = scratch + (size_t)blockIdx.y * img_bytes;
-  const int nsel = nf_meta(img)->n_sel;
-  int cb = 0, g = (int)blockIdx.x;
-  while (g >= cb / 4 + 1) { g -= cb / 4 + 1; ++cb; }  // (<= 32 scalar steps)
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int rb = 4 * g + wave;
-  if (cb * 64 >= nsel || rb > cb) return;  // (no workgroup barrier below: waves are independent)
-  const int j = cb * 64 + lane, i0 = rb * 64;
-  const bool valid = j < nsel;
-  const float4 me = valid ? nf_cbox(img)[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float marea = valid ? nf_area(img)[j] : 0.f;
-  {
-    const int i = i0 + lane;  // (i0 + 63 < nsel whenever rb < cb; the diagonal tile masks its tail through `valid` and i < lane)
-    const float4 rbx = i < nsel ? nf_cbox(img)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    rows[wave][lane] = KeptBox{rbx.x, rbx.y, rbx.z, rbx.w, i < nsel ? nf_area(img)[i] : 0.f};
+// v_min_f32 / v_max_f32 as the hardware does them (IEEE mode: a NaN operand yields the other operand, like fminf / fmaxf), without the
+// canonicalising `v_max x, x` the compiler puts in front of every fminf / fmaxf on values it cannot prove free of signalling NaNs.
+__device__ __forceinline__ float nf_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nf_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b)); return r; }
+__device__ __forceinline__ float nf_max0(float b) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(b)); return r; }
+__device__ __forceinline__ float nf_readlane(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+
+// One 256-thread workgroup per 64 x 64 tile (cb, rb), its 4 waves take 16 rows each; workgroup g of an image walks the tiles
+// g, g + gridDim.x, ... of the image's OWN triangle (nothing is launched per tile, so an image with few candidates costs a few tiles).
+// Row operands are wave-uniform (v_readlane of the row box held by lane i), so every test is arithmetic against scalar operands, and
+// it is torchvision's expression itself -- inter = max(0, w) * max(0, h), union = (area_i + area_j) - inter -- with the division
+// replaced by q = inter * rcp(union): |q - thr| > band decides (yes = q > thr); only when some lane of the wave lands inside the
+// band (or q is NaN: 0/0, NaN boxes), or an area is not a sane positive number, the division itself runs for that row.
+// Why that is exact: with both areas > 1e-30 the union is a normal number >= ~max(area) (inter <= min(area) up to rounding), so q is
+// within ~2.5 ulp (3e-7 relative) of inter / union and the correctly rounded quotient within 0.5 ulp of it: outside
+// band = 1e-6 * thr the comparison `fl(inter / union) > thr` is already decided.  (thr < 1e-6: band = inf, always the division.)
+#define NF_MASK_WG 64
+__global__ __launch_bounds__(256) void nf_mask_kernel(float thr, float band, const float4* __restrict__ cbox_all, const float* __restrict__ area_all,
+                                                      const NfMeta* __restrict__ meta_all, unsigned long long* __restrict__ mask_all, size_t img_bytes) {
+  __shared__ unsigned part[2][4][64];
+  const size_t ioff = (size_t)blockIdx.y * img_bytes;
+  const int nsel = reinterpret_cast<const NfMeta*>(reinterpret_cast<const char*>(meta_all) + ioff)->n_sel;
+  const int NB = (nsel + 63) >> 6, ntiles = NB * (NB + 1) / 2;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const float4* __restrict__ cbox = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cbox_all) + ioff);
+  const float* __restrict__ carea = reinterpret_cast<const float*>(reinterpret_cast<const char*>(area_all) + ioff);
+  unsigned long long* __restrict__ mask = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(mask_all) + ioff);
+  int par = 0;
+  for (int t = (int)blockIdx.x; t < ntiles; t += (int)gridDim.x, par ^= 1) {
+    int cb = (int)((__builtin_sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);  // t = cb (cb + 1) / 2 + rb, 0 <= rb <= cb
+    while (cb * (cb + 1) / 2 > t) --cb;
+    while ((cb + 1) * (cb + 2) / 2 <= t) ++cb;
+    const int rb = t - cb * (cb + 1) / 2;
+    const int j = cb * 64 + lane, i = rb * 64 + lane;
+    const bool valid = j < nsel;
+    const float4 me = valid ? cbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float marea = valid ? carea[j] : 1.f;
+    // Rows / columns whose area is not a sane positive finite number (tiny, zero, negative, huge, NaN) make the whole tile take the
+    // division (band = inf): with every area in (1e-30, 1e30) all extents are finite, the union is a normal number >= ~max(area) and q
+    // is never NaN.  (Rows >= nsel -- only on the last diagonal tile -- hold stale records: their bits are masked below, whatever they are.)
+    const float rar_l = i < nsel ? carea[i] : 1.f;
+    const bool sane = __builtin_amdgcn_ballot_w64(!(rar_l > 1e-30f && rar_l < 1e30f) || !(marea > 1e-30f && marea < 1e30f)) == 0ull;
+    const float band_t = sane ? band : INFINITY;
+    // the wave's 16 row boxes: wave-uniform addresses -> wide scalar loads, the operands below are SGPRs (no per-row lane broadcasts)
+    const float4* __restrict__ rp = cbox + (rb * 64 + 16 * wave);
+    const float* __restrict__ ap = carea + (rb * 64 + 16 * wave);
+    unsigned bits = 0u;  // bit (15 - r) = row r (rows are shifted in from the right; reversed below)
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 8) {
+      float4 rbx[8];
+      float rar[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) { rbx[g] = rp[r0 + g]; rar[g] = ap[r0 + g]; }
+      float inter[8], uni[8], d[8];
+      float closest = INFINITY;  // min over the 8 rows of |q - thr|
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float w = nf_max0(__fsub_rn(nf_min(rbx[g].z, me.z), nf_max(rbx[g].x, me.x)));
+        const float h = nf_max0(__fsub_rn(nf_min(rbx[g].w, me.w), nf_max(rbx[g].y, me.y)));
+        inter[g] = __fmul_rn(w, h);
+        uni[g] = __fsub_rn(__fadd_rn(rar[g], marea), inter[g]);
+        d[g] = __fsub_rn(__fmul_rn(inter[g], __builtin_amdgcn_rcpf(uni[g])), thr);
+      }
+#pragma unroll
+      for (int g = 0; g < 8; g += 2) closest = __builtin_fminf(closest, __builtin_fminf(__builtin_fabsf(d[g]), __builtin_fabsf(d[g + 1])));  // (v_min3_f32)
+      if (__builtin_amdgcn_ballot_w64(closest > band_t) != ~0ull) {  // (rare, wave-uniform) some lane is not sure: the reference's own expression
+#pragma unroll
+        for (int g = 0; g < 8; ++g) d[g] = __fdiv_rn(inter[g], uni[g]) > thr ? 1.f : -1.f;  // (inter, uni ARE the reference's operands)
+      }
+#pragma unroll
+      for (int g = 0; g < 8; ++g)  // bits = 2 * bits + (d > 0): compare into VCC, add with carry-in
+        asm("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(d[g]) : "vcc");
+    }
+    bits = __builtin_bitreverse32(bits) >> 16;  // row r -> bit r
+    if (rb == cb) {  // the diagonal tile: only EARLIER candidates (rows 16 * wave + r < lane) count
+      const int nlow = lane - 16 * wave;
+      bits &= nlow >= 16 ? 0xFFFFu : nlow <= 0 ? 0u : ((1u << nlow) - 1u);
+    }
+    part[par][wave][lane] = bits;
+    __syncthreads();  // (one barrier per tile: the partials alternate between two buffers)
+    if (wave == 0) {
+      const unsigned long long word = (unsigned long long)part[par][0][lane] | ((unsigned long long)part[par][1][lane] << 16) |
+                                      ((unsigned long long)part[par][2][lane] << 32) | ((unsigned long long)part[par][3][lane] << 48);
+      mask[(size_t)t * 64 + lane] = valid ? word : 0ull;
+    }
   }
-  __builtin_amdgcn_wave_barrier();
-  const int nrow = min(64, nsel - i0);
-  const int lim = rb == cb ? lane : 64;  // the diagonal tile: only earlier candidates
-  unsigned long long word = 0ull;
-#pragma unroll 4
-  for (int i = 0; i < nrow; ++i) {
-    const KeptBox r = rows[wave][i];
-    if (i < lim && iou_gt_fast(r.x1, r.y1, r.x2, r.y2, r.area, me.x, me.y, me.z, me.w, marea, thr, thr_lo, thr_hi)) word |= 1ull << i;
-  }
-  nf_mask(img)[((size_t)(cb * (cb + 1) / 2 + rb)) * 64 + lane] = valid ? word : 0ull;
 }
 
 struct NfResShared {
-  unsigned long long buf[8][NF_NB][64];  // the mask words of 8 column blocks (128 KB)
-  unsigned long long kw[NF_NB];          // kept bits per column block
-  int kpre[NF_NB + 1];                   // kept boxes before each block
+  unsigned long long buf[8][8][64];  // the mask words among the 8 column blocks in flight: [c][rb - cb0] (32 KB)
+  unsigned long long hit[16][64];    // phase A: per wave, "an earlier kept box (of an earlier group of 8 blocks) overlaps me"
+  unsigned long long kw[NF_NB];      // kept bits per column block
+  int kpre[NF_NB + 1];               // kept boxes before each block
   int nkept, stop;
 };
 
-__global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P, const float* __restrict__ boxsrc, long img_stride, int max_det, int max_nms,
-                                                          const int* __restrict__ cls_id, char* __restrict__ scratch, size_t img_bytes, float* __restrict__ out_boxes,
-                                                          int* __restrict__ out_count, int* __restrict__ out_index) {
+// ... and, for an image the K best candidates could not complete (fewer than max_det kept while more candidates exist), the general
+// algorithm (nms_general_body) right here, from scratch, in the same workgroup: no extra launch on the common path.
+__global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P, long nkeys, const float* __restrict__ boxsrc, long img_stride, float iou_thres, int max_det,
+                                                          int max_nms, float max_wh, int agnostic, int target, int cap, int partition,
+                                                          const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id, char* __restrict__ scratch,
+                                                          size_t img_bytes, float* __restrict__ out_boxes, int* __restrict__ out_count, int* __restrict__ out_index) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   NfResShared& S = *reinterpret_cast<NfResShared*>(smem);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -278,18 +401,33 @@ __global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P,
   __syncthreads();
   for (int cb0 = 0; cb0 < NB; cb0 += 8) {
     const int ncb = min(8, NB - cb0);
-    for (int c = 0; c < ncb; ++c)
-      for (int rb = wave; rb <= cb0 + c; rb += 16) S.buf[c][rb][lane] = mask[((size_t)((cb0 + c) * (cb0 + c + 1) / 2 + rb)) * 64 + lane];
+    {
+      // phase A (all 16 waves): the kept-words of every EARLIER group of 8 blocks are final -- waves (c, c + 8) fold the words
+      // (cb0 + c, rb < cb0) against them straight from memory (independent loads), half of the row blocks each
+      const int c = wave & 7, cb = cb0 + c;
+      unsigned long long acc = 0ull;
+      if (c < ncb) {
+#pragma unroll 4
+        for (int rb = wave >> 3; rb < cb0; rb += 2) acc |= mask[((size_t)(cb * (cb + 1) / 2 + rb)) * 64 + lane] & S.kw[rb];
+      }
+      S.hit[wave][lane] = acc;
+      // ... and the words among the group itself go to LDS for the sequential part
+      for (int q = wave; q < ncb * (ncb + 1) / 2; q += 16) {
+        int cc = 0;
+        while ((cc + 1) * (cc + 2) / 2 <= q) ++cc;
+        const int r = q - cc * (cc + 1) / 2, cbq = cb0 + cc;
+        S.buf[cc][r][lane] = mask[((size_t)(cbq * (cbq + 1) / 2 + cb0 + r)) * 64 + lane];
+      }
+    }
     __syncthreads();
     if (wave == 0) {  // the sequential part: one wave, no barrier inside (it reads kept-words it wrote itself)
       int nk = S.nkept;
       for (int c = 0; c < ncb && nk < max_det; ++c) {
         const int cb = cb0 + c;
-        unsigned long long hit = 0ull;
-#pragma unroll 4
-        for (int rb = 0; rb < cb; ++rb) hit |= S.buf[c][rb][lane] & S.kw[rb];
+        unsigned long long hit = S.hit[c][lane] | S.hit[c + 8][lane];
+        for (int r = 0; r < c; ++r) hit |= S.buf[c][r][lane] & S.kw[cb0 + r];
         const bool alive = (cb * 64 + lane < nsel) && hit == 0ull;
-        unsigned long long km = nms_resolve(S.buf[c][cb][lane], alive);
+        unsigned long long km = nms_resolve(S.buf[c][c][lane], alive);
         const int room = max_det - nk;
         if (__popcll(km) > room) {  // keep the first `room` of them (earlier candidates first); nothing after matters
           unsigned long long t = km;
@@ -334,9 +472,15 @@ __global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P,
   for (int r = nk * 6 + tid; r < max_det * 6; r += 1024) ob[r] = 0.f;
   if (out_index)
     for (int r = nk + tid; r < max_det; r += 1024) out_index[(long)b * max_det + r] = -1;
+  // complete when max_det boxes were found or every candidate the reference would look at (all of them, capped at max_nms) was among the K
+  const bool done = nk >= max_det || nsel == ntotal || nsel >= max_nms;  // (workgroup-uniform)
   if (tid == 0) {
     out_count[b] = nk;
-    // complete when max_det boxes were found or every candidate the reference would look at (all of them, capped at max_nms) was among the K
-    meta->done = (nk >= max_det || nsel == ntotal || nsel >= max_nms) ? 1 : 0;
+    meta->done = done ? 1 : 0;
+  }
+  if (!done) {
+    __syncthreads();  // (LDS changes hands; the rows written above are rewritten below)
+    nms_general_body(smem, nc, A, P, nkeys, 0, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic, target, cap, partition, 0, gkeys, cls_id, out_boxes,
+                     out_count, out_index);
   }
 }

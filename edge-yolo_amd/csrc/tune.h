@@ -31,6 +31,7 @@ struct EyTune {
   long stem_mfma = 1;           // MFMA stem kernel (0 = VALU stem)
   long linattn_mfma = 1;        // MFMA linear-attention kernel (0 = fp32 VALU kernel)
   long softattn_mfma = 1;       // MFMA softmax-attention kernel (0 = fp32 VALU kernel)
+  long nms_mask_wg = 0;         // nf_mask: workgroups per image (0 = the measured default)
   long nms_fast_k = 2048;       // predict-mode NMS: the three-kernel fast path over the best K candidates per image (<= 2048; 0 = general kernel only)
 };
 extern EyTune g_ey_tune;
