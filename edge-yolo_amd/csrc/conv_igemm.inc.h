@@ -935,6 +935,145 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// 3x3 "stream" kernel (f16, one source, Cin = 64 * UPT, stride 1 or 2): weight-stationary like conv_ws_kernel, but shaped for the
+// K = 576 ... 2304 convs (backbone down-sampling layers 3/5/7/17/20, the Detect box towers) whose time the tile kernel above spends
+// outside the MFMA loop (halo staging and two barriers per 32-channel chunk, a prologue and an epilogue every workgroup reaches at
+// the same moment).  Here a 512-thread workgroup stages its [16*NT][K] weight tile into LDS ONCE and its 8 waves then run
+// independently for the life of the grid -- no barrier after the staging, so the waves drift apart and one wave's epilogue (SiLU on
+// the VALU, stores) runs beside its SIMD partner's MFMAs:
+//   * wave tile = 16*MT consecutive output pixels (flattened over batch x rows x columns: no tile-shape waste on 20x20 maps) x 16*NT
+//     channels; A = weight fragments from LDS (NT ds_read_b128 per k-step, shared by MT*NT MFMAs), B = pixel fragments by
+//     range-checked buffer loads straight from L2 (padding taps / M tail = hardware zeros; a 3x3 stride-1 conv re-reads its input 9x
+//     through the vector-memory path, 2.25x at stride 2 -- 236 MB per launch at most for these layers, < 7 us of the 64 B/clk path);
+//   * K is walked in units of 2 k-steps (64 channels of one tap); a ring of NB unit buffers keeps NB - 1 units of pixel loads in
+//     flight ahead of the MFMAs (NB = 3 for the big layers; NB = 9 -- a whole row of taps -- where a layer has so few wave tiles that
+//     a wave's K walk is one dependent chain of memory round trips), and the ring does NOT drain between tiles: the last units of a
+//     tile prefetch the first ones of the wave's next tile, so its loads fly during the epilogue;
+//   * a workgroup owns a CONTIGUOUS run of wave tiles and its 8 waves take neighbouring tiles: the 9x (stride 1) / 2.25x (stride 2)
+//     re-reads of an input line come from waves of the same CU / XCD (L1 / L2 hits instead of Infinity-Cache round trips);
+//   * at most 256 VGPRs (2 waves per SIMD), grid = one workgroup per CU and channel tile.
+template <int NT, int MT, int UPT, int S, int NB>
+__global__ __launch_bounds__(512, 2) void conv3s_kernel(ConvP p) {
+  typedef f16 T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* wl = reinterpret_cast<T*>(smem);
+  constexpr int BN = 16 * NT, CIN = 64 * UPT, NU = 9 * UPT;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * BN;
+  {  // weight tile: one contiguous block (LDS row stride == packed row stride)
+    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    const int nvec = BN * (p.Kpad >> 3);
+    for (int v0 = threadIdx.x; v0 < nvec; v0 += 512 * 8) {
+      Vec8<T> w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].load(wg + (long)(v0 + u * 512) * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (v0 + u * 512 < nvec) w[u].store(wl + (v0 + u * 512) * 8);
+    }
+  }
+  __syncthreads();
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int hw = p.Ho * p.Wo;
+  const T* wlane = wl + r * p.LSw + 8 * g;
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc(p.src[0], p.srcBytes[0]);
+  const int Cs = p.srcCs[0], rowB = p.W * Cs * 2;  // bytes per input row
+
+  // per tile and pixel block: byte offset of the window origin (tap 0,0; may be "negative" = wraps, only used when the tap is valid)
+  // and the 9-bit mask of taps that fall inside the image
+  struct Desc { int base[MT]; unsigned vm[MT]; };
+  auto setup = [&](long tile, Desc& d) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long m = tile * (16 * MT) + mt * 16 + r;
+      const bool pv = m < M;
+      const long mm = pv ? m : 0;
+      const int b = (int)(mm / hw), rem = (int)(mm - (long)b * hw);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy0 = oy * S - 1, ix0 = ox * S - 1;
+      d.base[mt] = ((b * p.H + iy0) * p.W + ix0) * Cs * 2 + 16 * g;
+      unsigned vm = 0u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+        vm |= (pv && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? (1u << t) : 0u;
+      }
+      d.vm[mt] = vm;
+    }
+  };
+  Vec8<T> bq[NB][MT][2];
+  auto issue = [&](const Desc& d, int u, Vec8<T> (&bf)[MT][2]) {
+    const int tap = u / UPT, c0 = (u - tap * UPT) * 64;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int toff = ky * rowB + (kx * Cs + c0) * 2;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const unsigned vo = ((d.vm[mt] >> tap) & 1u) ? (unsigned)(d.base[mt] + toff) : EY_OOB;
+      BufLoad8<T>::load(bf[mt][0], rs, vo, 0);
+      BufLoad8<T>::load(bf[mt][1], rs, vo, 64);
+    }
+  };
+  f32x4 acc[MT][NT];
+  auto compute = [&](int u, const Vec8<T> (&bf)[MT][2]) {
+    const T* wk = wlane + u * 64;  // k = tap * CIN + c0 = u * 64
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Vec8<T> af[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) af[nt].load(wk + nt * 16 * p.LSw + ks * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16(af[nt], bf[mt][ks], acc[mt][nt]);
+    }
+  };
+
+  // workgroup b owns tiles [b * tpw, (b + 1) * tpw); wave w takes b * tpw + w, + 8, ...
+  const long tpw = (p.ntile + gridDim.x - 1) / gridDim.x, tend = min(p.ntile, (long)(blockIdx.x + 1) * tpw);
+  long tile = (long)blockIdx.x * tpw + wave;
+  if (tile >= tend) return;
+  Desc cur, nxt;
+  setup(tile, cur);
+#pragma unroll
+  for (int j = 0; j < NB - 1; ++j) issue(cur, j, bq[j]);
+  while (true) {
+    const long ntl = tile + 8;
+    const bool more = ntl < tend;
+    if (more) setup(ntl, nxt);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4)0.f;
+#pragma unroll 1
+    for (int u = 0; u < NU; u += NB) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int uu = u + j + NB - 1;
+        if (uu < NU) issue(cur, uu, bq[(j + NB - 1) % NB]);
+        else if (more) issue(nxt, uu - NU, bq[(j + NB - 1) % NB]);  // the next tile's first units: in flight during this tile's epilogue
+        compute(u + j, bq[j]);
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const long m = tile * (16 * MT) + mt * 16 + r;
+      if (m < M) {
+        const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+        const int oy = rem / p.Wo;
+        conv_epilogue<T, NT>(p, acc[mt], m, b, oy, rem - oy * p.Wo, ch0, 0);
+      }
+    }
+    if (!more) break;
+    cur = nxt;
+    tile = ntl;
+  }
+}
+
+// ================================================================================================================
 // Register-stationary 3x3 kernel for Cin == 16 (layer 1: 16->32 stride 2 at 320x320; the 16->8 sub-band convs): K = 144 is
 // nine 16-channel taps, i.e. nine v_mfma_f32_16x16x16_f16 per 16 pixels per 16 output channels, and the whole weight tile is
 // 9*NT two-register fragments -- it lives in registers.  A persistent wave walks 16-pixel row segments: 9 range-checked 8-byte
@@ -1672,6 +1811,74 @@ static int dispatch_c3r(ConvP p, int ngroup, hipStream_t st) {
   return 0;
 }
 
+// ---- 3x3 stream kernel dispatch (f16, Cin in {64, 128, 256}, one source, no groups)
+template <int NT, int MT, int UPT, int S, int NB>
+static int c3s_launch2(ConvP p, hipStream_t st) {
+  const size_t lds = (size_t)16 * NT * p.LSw * 2;
+  static size_t reserved = 0;
+  if (lds > 64 * 1024 && lds > reserved) {
+    if (hipFuncSetAttribute((const void*)conv3s_kernel<NT, MT, UPT, S, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    reserved = lds;
+  }
+  const long M = (long)p.B * p.Ho * p.Wo;
+  p.ntile = (M + 16 * MT - 1) / (16 * MT);
+  const int ny = conv_cout_pad(p.Cout) / (16 * NT);
+  long gx = 256 / ny;  // one workgroup per CU over all channel tiles
+  if (gx < 1) gx = 1;
+  if (gx * 8 > p.ntile) gx = (p.ntile + 7) / 8;
+  hipLaunchKernelGGL((conv3s_kernel<NT, MT, UPT, S, NB>), dim3((unsigned)gx, (unsigned)ny, 1), dim3(512), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(c3s): %s", hipGetErrorString(e_));
+  g_last_variant = 8000 + NT * 100 + MT * 10 + (NB == 9 ? 5 : 0) + S;
+  return 1;
+}
+template <int NT, int MT, int UPT, int NB>
+static int c3s_launch1(const ConvP& p, hipStream_t st) { return p.stride == 1 ? c3s_launch2<NT, MT, UPT, 1, NB>(p, st) : c3s_launch2<NT, MT, UPT, 2, NB>(p, st); }
+template <int NT, int MT, int NB>
+static int c3s_launch0(const ConvP& p, hipStream_t st) {
+  switch (p.srcC[0]) {
+    case 64: return c3s_launch1<NT, MT, 1, NB>(p, st);
+    case 128: return c3s_launch1<NT, MT, 2, NB>(p, st);
+    default: return c3s_launch1<NT, MT, 4, NB>(p, st);
+  }
+}
+template <typename T>
+static int dispatch_c3s(ConvP p, int ngroup, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) return 0;
+  else {
+    if (!tune().c3s || p.k != 3 || p.nsrc != 1 || p.srcUp[0] || ngroup != 1) return 0;
+    const int Cin = p.srcC[0];
+    if (Cin != 64 && Cin != 128 && Cin != 256) return 0;
+    const int ntp = conv_nt(p.Cout);
+    if (conv_cout_pad(p.Cout) != p.Cout && conv_cout_pad(p.Cout) / 16 != ntp) return 0;
+    // widest channel tile (a whole number of 16-row blocks of the packing tile) whose [16*NT][Kpad] weights fit one CU's LDS
+    int nt = 0;
+    const int opts[3] = {4, 2, 1};
+    for (int i = 0; i < 3 && !nt; ++i)
+      if (opts[i] <= ntp && ntp % opts[i] == 0 && (size_t)16 * opts[i] * p.Kpad * 2 <= 156 * 1024) nt = opts[i];
+    if (!nt) return 0;
+    const long npix = (long)p.B * p.H * p.W;
+    const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * 2L;
+    if (bytes >= (1L << 31) || (long)conv_cout_pad(p.Cout) * p.Kpad * 2L >= (1L << 31)) return 0;
+    p.srcBytes[0] = (unsigned)bytes;
+    p.NTpack = ntp;
+    p.LSw = ws_ls(p.Kpad);
+    const long M = (long)p.B * p.Ho * p.Wo;
+    // Measured at batch 32 (tools/c3s_bench.sh, profiles/r03_c3s_vs_tile.txt): the stream kernel wins where the layer is big enough to
+    // keep every CU streaming -- the stride-2 down-sampling convs (layer 3: 68 -> 47 us, 5: 56 -> 38, 7: 34 -> 27, 17: 19.5 -> 16) -- and
+    // loses to the LDS-halo tile kernel at stride 1 (every input line goes through the vector-memory path 9 times: L2 hits, but at
+    // ~30 B/clk per CU that is 13 us for the 80x80 box-tower convs) and on the smallest maps.  c3s = 2 forces it everywhere (tests).
+    const long work = M * (conv_cout_pad(p.Cout) / (16 * nt));
+    if (tune().c3s < 2 && (p.stride != 2 || work < tune().c3s_min_work)) return 0;
+    // wave tile: 4 pixel blocks per wave on the big layers, 2 (more, smaller wave tiles) otherwise
+    long cfg = tune().c3s_cfg;  // (developer knob: MT * 10 + ring depth)
+    if (!cfg) cfg = (nt == 4 && M >= tune().c3s_mt4_m) ? 43 : 23;
+    if (nt == 4) return cfg == 43 ? c3s_launch0<4, 4, 3>(p, st) : c3s_launch0<4, 2, 3>(p, st);
+    if (nt == 2) return c3s_launch0<2, 2, 3>(p, st);
+    return c3s_launch0<1, 2, 3>(p, st);
+  }
+}
+
 // ---- small-M dispatch
 template <typename T, int NT>
 static int small_launch(ConvP p, int ngroup, hipStream_t st) {
@@ -1910,6 +2117,8 @@ static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   if (sm != 0) return sm < 0 ? sm : EY_OK;
   const int cr = dispatch_c3r<T>(p, ngroup, st);
   if (cr != 0) return cr < 0 ? cr : EY_OK;
+  const int cs = dispatch_c3s<T>(p, ngroup, st);
+  if (cs != 0) return cs < 0 ? cs : EY_OK;
   const int tl = dispatch_tile<T>(p, ngroup, st);
   if (tl != 0) return tl < 0 ? tl : EY_OK;
   const int halo = dispatch_halo<T>(p, ngroup, st);

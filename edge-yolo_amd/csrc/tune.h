@@ -15,6 +15,10 @@ struct EyTune {
   long tile_s2_minc = 64;       // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = 40000;    // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
   long grid_div = 1;            // persistent kernels: launch 1/grid_div of the resident slots
+  long c3s = 1;                 // 3x3 stream kernel (weights LDS-resident, pixels straight from L2) for Cin in {64, 128, 256} (0 = off)
+  long c3s_mt4_m = 100000;      // ... 4 pixel blocks per wave from this many output pixels (else 2)
+  long c3s_min_work = 40000;    // ... only for stride-2 convs with at least this many (output pixels x channel tiles); c3s = 2: everywhere
+  long c3s_cfg = 0;             // ... developer knob: force MT * 10 + ring depth (43, 23); 0 = the rule above
   long c3r = 1;                 // register-stationary 3x3 kernel for Cin == 16 (0 = off)
   long tile_minwg = 400;        // stride-1 tile kernel: halve the channel tile while fewer workgroups than this would be launched
   long tile_flat = 1;           // stride-1 tile kernel: flattened tiles fitted to the map (0 = fixed 8 x 32)

@@ -324,3 +324,54 @@ def test_pointwise_chain_kernel_agrees_with_two_f32_convs(M, cin, cout, h, w):
     got = _ops.conv_pw_chain(_Plain(c2h), x.cuda(), c1h.folded, L.ACT_SILU, lambda: fold_bn(c2h.weight, c2h.bias, None), L.ACT_NONE, out)
     assert got is not None
     torch.testing.assert_close(got.float().cpu(), want, rtol=3e-3, atol=3e-3 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("c1,c2,s,hw,B", [(64, 64, 2, 160, 4), (128, 128, 2, 80, 4), (128, 256, 2, 40, 8), (64, 64, 2, 80, 5), (128, 128, 2, 40, 7),
+                                          (64, 64, 1, 80, 3), (128, 64, 1, 40, 6), (256, 64, 1, 20, 9), (64, 64, 1, 20, 32), (64, 32, 1, 20, 11), (256, 64, 1, 21, 3)])
+def test_conv3_stream_kernel_at_real_shapes(M, c1, c2, s, hw, B):
+    """The 3x3 stream kernel (conv3s_kernel: LDS-resident weights, pixel fragments straight from L2, ring prefetch across tiles) at the
+    network's own K >= 576 shapes (layers 3/5/7/17/20, Detect box towers; odd map / batch sizes for the M tail): against the fp32 oracle
+    and against the kernels it replaces (tunable c3s = 0) -- the two f16 paths differ only by fp32 summation order."""
+    from edge_yolo_amd import _lib as L
+    m = M.Conv(c1, c2, 3, s)
+    sd = load_synth(m, "c3s")
+    x = synth.synth_images(B, hw, hw, seed=3, c=c1) - 0.5
+    xd = x.to("cuda", torch.float16)
+    m = to_dev(m, torch.float16)
+    m.fuse_bn()
+    lib = L.lib()
+    try:
+        L.check(lib.ey_tune_set(b"c3s", 2), "tune")  # 2 = every shape the kernel takes (the default rule keeps it to the big stride-2 layers)
+        got = m(xd)
+        assert lib.ey_conv_last_variant() // 1000 == 8, f"stream kernel not dispatched (variant {lib.ey_conv_last_variant()})"
+        L.check(lib.ey_tune_set(b"c3s", 0), "tune")
+        old = m(xd)
+        assert lib.ey_conv_last_variant() // 1000 != 8
+    finally:
+        L.check(lib.ey_tune_set(b"c3s", 1), "tune")
+    torch.cuda.synchronize()
+    assert float((got.float() - old.float()).abs().max()) <= 2e-3 * max(1.0, float(old.float().abs().max()))
+    if B * hw * hw <= 60000:
+        check(got, om.conv(sd, "c3s", x.half().float(), 3, s), torch.float16, what=f"Conv {c1}->{c2} k3s{s} {hw}x{hw}")
+
+
+def test_conv3_stream_kernel_views_residual_act(M):
+    """stream kernel with out= into a channel slice, a channel-sliced input view, residual add and no activation."""
+    from edge_yolo_amd import _lib as L
+    m = M.Conv(64, 64, 3, 1, act=False)
+    sd = load_synth(m, "c3sv")
+    x = synth.synth_images(2, 22, 18, seed=5, c=128) - 0.5
+    xd = x.to("cuda", torch.float16)
+    m = to_dev(m, torch.float16)
+    buf = L.empty_nhwc(2, 192, 22, 18, torch.float16, "cuda")
+    buf.zero_()
+    xin = L.as_nhwc(xd)[:, 64:]
+    L.check(L.lib().ey_tune_set(b"c3s", 2), "tune")
+    try:
+        m(xin, out=buf[:, 64:128], res=xin)
+        assert L.lib().ey_conv_last_variant() // 1000 == 8
+    finally:
+        L.check(L.lib().ey_tune_set(b"c3s", 1), "tune")
+    want = x[:, 64:].half().float() + om.conv(sd, "c3sv", x[:, 64:].half().float(), 3, 1, act=False)
+    check(buf[:, 64:128], want, torch.float16)
+    assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 128:].abs().max()) == 0
