@@ -27,8 +27,8 @@ class _NoTrace:
 _NT = _NoTrace()
 
 
-def _tr(kernel, nbytes, flops=0, note=""):
-    return TRACE.launch(kernel, nbytes, flops, note) if TRACE is not None else _NT
+def _tr(kernel, nbytes, flops=0, note="", kernels=1):
+    return TRACE.launch(kernel, nbytes, flops, note, kernels) if TRACE is not None else _NT
 
 
 def _nb(*tensors):
@@ -180,7 +180,9 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         with rec:
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
             lv = L.lib().ey_conv_last_variant()
-            if lv >= 7000:
+            if lv >= 8000:
+                rec.kernel = f"conv3s_kernel<{lv % 1000 // 100},{lv % 100 // 10},{lv % 10}>"
+            elif lv >= 7000:
                 rec.kernel = f"conv3r_kernel<{lv % 1000 // 10},{lv % 10}>"
             elif lv >= 6000:
                 rec.kernel = f"conv3_tile_kernel<{tn},{lv % 1000 // 10},{lv % 10}>"
@@ -526,7 +528,9 @@ def nms_candidates(cand, iou_thres, max_det, max_nms, max_wh, agnostic):
     boxes = torch.empty((cand.B, max_det, 6), dtype=torch.float32, device=dev)
     count = torch.empty((cand.B,), dtype=torch.int32, device=dev)
     index = torch.empty((cand.B, max_det), dtype=torch.int32, device=dev)
-    with _tr("nms_select_greedy_kernel", cand.buf.numel() + _nb(boxes)):
+    # predict mode = the three-kernel fast path (csrc/nms_fast.inc.h), bracketed as one operator
+    alg = cand.B * ((cand.A + 255) // 256 * 256 * 12 + cand.A * 16)  # keys + class ids + boxes (the tail of the buffer is scratch)
+    with _tr("nms_fast(nf_select+nf_mask+nf_resolve)", alg + _nb(boxes), kernels=3):
         L.check(L.lib().ey_nms_candidates(cand.B, cand.nc, cand.A, cand.buf.data_ptr(), cand.buf.numel(), float(iou_thres), int(max_det), int(max_nms), float(max_wh),
                                           int(bool(agnostic)), boxes.data_ptr(), count.data_ptr(), index.data_ptr(), L.stream()), "ey_nms_candidates")
     return boxes, count, index

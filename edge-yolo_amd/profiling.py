@@ -15,15 +15,16 @@ class Trace:
     def __init__(self):
         self.records = []  # (kernel, alg_bytes, alg_flops, start_event, end_event)
 
-    def launch(self, kernel, alg_bytes, alg_flops, note=""):
-        return _Launch(self, kernel, alg_bytes, alg_flops, note)
+    def launch(self, kernel, alg_bytes, alg_flops, note="", kernels=1):
+        return _Launch(self, kernel, alg_bytes, alg_flops, note, kernels)
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for k, b, f, s, e, _ in self.records:
-            a = agg.setdefault(k, {"launches": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
+        for k, b, f, s, e, _, nk in self.records:
+            a = agg.setdefault(k, {"launches": 0, "kernels": 0, "ms": 0.0, "bytes": 0.0, "flops": 0.0})
             a["launches"] += 1
+            a["kernels"] += nk
             a["ms"] += s.elapsed_time(e)
             a["bytes"] += b
             a["flops"] += f
@@ -31,8 +32,8 @@ class Trace:
 
 
 class _Launch:
-    def __init__(self, tr, kernel, b, f, note=""):
-        self.tr, self.kernel, self.b, self.f, self.note = tr, kernel, b, f, note
+    def __init__(self, tr, kernel, b, f, note="", kernels=1):
+        self.tr, self.kernel, self.b, self.f, self.note, self.kernels = tr, kernel, b, f, note, kernels
 
     def __enter__(self):
         self.s = torch.cuda.Event(enable_timing=True)
@@ -41,7 +42,7 @@ class _Launch:
 
     def __exit__(self, *a):
         self.e.record()
-        self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e, self.note))
+        self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e, self.note, self.kernels))
 
 
 @contextlib.contextmanager
@@ -108,9 +109,11 @@ def step_roofline(step_fn, steps, ms_per_step, hbm_peak_gbs, mfma_peak_tflops, c
         avg_us, bytes_per, flops_per = a["ms"] * 1e3 / n, a["bytes"] / n, a["flops"] / n
         r = {"kernel": k, "launches_per_step": round(n / steps, 2), "avg_launch_us": round(avg_us, 3), "ms_per_step": round(a["ms"] / steps, 4),
              "share": round(a["ms"] / total, 4), "alg_bytes_per_launch": int(bytes_per), "alg_flops_per_launch": int(flops_per)}
+        if a["kernels"] != n:  # an operator that is several kernels behind one C call (bracketed as a whole): rocprofv3 splits it (profiles/)
+            r["kernels_per_launch"] = round(a["kernels"] / n, 2)
         r.update(_price(bytes_per, flops_per, avg_us, hbm_peak_gbs, mfma_peak_tflops))
         rows.append(r)
-    top = rows[0]
+    top = next((r for r in rows if "kernels_per_launch" not in r), rows[0])  # a single kernel (composite operators are priced in `table`)
     out = {"kernel": top["kernel"], "launches_per_step": top["launches_per_step"], "avg_launch_us": top["avg_launch_us"],
            "share_of_traced_device_time": top["share"]}
     out.update({k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac", "alg_bytes_per_launch", "alg_flops_per_launch")})
@@ -124,7 +127,7 @@ def step_roofline(step_fn, steps, ms_per_step, hbm_peak_gbs, mfma_peak_tflops, c
     step_bytes = sum(a["bytes"] for a in agg.values()) / steps
     step_flops = sum(a["flops"] for a in agg.values()) / steps
     sec = ms_per_step * 1e-3
-    out["step"] = {"launches_per_step": round(sum(a["launches"] for a in agg.values()) / steps, 1), "traced_device_ms_per_step": round(total / steps, 4),
+    out["step"] = {"launches_per_step": round(sum(a["kernels"] for a in agg.values()) / steps, 1), "traced_device_ms_per_step": round(total / steps, 4),
                    "alg_bytes_per_step": int(step_bytes), "alg_flops_per_step": int(step_flops),
                    "hbm_frac": round(step_bytes / sec / (hbm_peak_gbs * 1e9), 4), "mfma_frac": round(step_flops / sec / (mfma_peak_tflops * 1e12), 4),
                    "ms_per_step": ms_per_step}
