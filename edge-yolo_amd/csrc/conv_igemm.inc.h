@@ -13,6 +13,7 @@
 // Pixels are fragment-shaped global loads (each wave owns its pixels; activations are read once because one block
 // covers all of Cout up to 128); the weight tile shared by the 4 waves goes through LDS.
 #include "common.h"
+#include <type_traits>
 
 struct ConvP {
   int B, H, W, Ho, Wo, Cout, k, stride, pad, act, nsrc;
@@ -935,6 +936,220 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// 3x3 persistent tile kernel for Cin = 64, stride 1 (f16): the Detect box-tower convs (64->64 at 80x80 / 40x40 / 20x20) and the
+// other K = 576 stride-1 convs.  Phase ablation of this kernel's first version (profiles/r03_conv3p_ablation.txt): of 37 us at 80x80,
+// batch 32, the EPILOGUE was ~20 us and the K loop ~12 -- 13 M outputs x (bias, v_exp, v_rcp, 2 multiplies, convert) on one wave per
+// SIMD with nothing beside it, then 16-byte stores at a 32-byte stride; the tile kernel above pays the same, plus a restaged 9-tap
+// weight block per 32-channel chunk of every tile between two barriers per chunk.  Here:
+//   * one 256-thread workgroup per CU, persistent over its tiles; the whole [9][64][64] weight block of its channel tile sits in LDS
+//     for the life of the workgroup (staged once) next to ONE all-channel halo buffer (<= 340 pixels x 64 ch): a tile is 18 k-steps
+//     x 16 MFMAs per wave between two LDS-only barriers (ey_lds_barrier: the vector-memory queue is not drained), the operand
+//     fragments of step k + 1 are read while step k multiplies, the next tile's halo is requested before the K loop;
+//   * FAST (bias + SiLU, no residual / resize-add, 16-byte-aligned full channel tile: every conv this kernel is dispatched for in the
+//     network): the EPILOGUE IS DEFERRED AND INTERLEAVED -- the finished accumulators of tile i move to a second register set and
+//     are activated, converted and stored in 16 branch-free quarters (4 outputs per lane each) placed behind k-steps 0..15 of tile
+//     i + 1, and sched_group_barrier pins "1 MFMA, 2 VALU" so the v_exp / v_rcp chains issue in the MFMAs' shadow (an MFMA holds
+//     the vector issue port 8 of its 16 cycles).  Stores are range-checked buffer stores (partial tiles / first tile: offset out of
+//     range -> dropped by the hardware), so the K loop stays ONE basic block.  Same arithmetic as conv_epilogue (bit-identical).
+//   * row pitch of both LDS arrays = 80 halves = 10 16-byte units: 2 (mod 4) units is conflict-free for ds_read_b128's lane groups
+//     (SQ_LDS_BANK_CONFLICT = 0; the ODD pitch of the older kernels is a 2-way conflict: 54 % of the tile kernel's LDS cycles).
+// Tile geometry = the flattened tTR x tTC pixel slots of conv3_tile_kernel (chosen on the host per map size).
+template <int NT, bool FAST>
+__global__ __launch_bounds__(256, 1) void conv3p_kernel(ConvP p) {
+  typedef f16 T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int MT = 4, CP = 80, NHV = (340 * 8 + 255) / 256;
+  T* wl = reinterpret_cast<T*>(smem);            // [9][16*NT][CP]
+  T* hl = wl + 9 * 16 * NT * CP;                 // [<= 340 halo pixels][CP]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, g = lane >> 4;
+  const int n_base = blockIdx.y * (16 * NT);
+  const int tTR = p.tTR, tTC = p.tTC, hHR = tTR + 2, hHC = tTC + 2;
+  const float inv_hc = 1.0f / (float)hHC, inv_tc = 1.0f / (float)tTC;
+  const int tilesX = (p.Wo + tTC - 1) / tTC, tilesY = (p.Ho + tTR - 1) / tTR, tiles_img = tilesX * tilesY;
+  const int ntiles = p.B * tiles_img;  // (< 2^31: checked on the host)
+  const __amdgpu_buffer_rsrc_t rs = ey_rsrc(p.src[0], p.srcBytes[0]);
+  {  // weights: packed rows [n_base + row][tap * 64 + c] -> LDS [tap][row][CP]; every vector requested before the first LDS store
+    const T* wg = (const T*)p.w + (long)n_base * p.Kpad;
+    constexpr int NWV = 9 * 16 * NT * 8 / 256;
+    Vec8<T> w[NWV];
+#pragma unroll
+    for (int u = 0; u < NWV; ++u) {
+      const int v = threadIdx.x + u * 256, cv = v & 7, row = (v >> 3) % (16 * NT), tap = (v >> 3) / (16 * NT);
+      w[u].load(wg + (long)row * p.Kpad + tap * 64 + cv * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < NWV; ++u) {
+      const int v = threadIdx.x + u * 256, cv = v & 7, row = (v >> 3) % (16 * NT), tap = (v >> 3) / (16 * NT);
+      w[u].store(wl + (tap * 16 * NT + row) * CP + cv * 8);
+    }
+  }
+  // halo vectors of this thread: LDS element offset (tile independent) and (row, column) inside the halo
+  int hlo[NHV], hyx[NHV];
+#pragma unroll
+  for (int u = 0; u < NHV; ++u) {
+    const int v = threadIdx.x + u * 256, px = v >> 3, cv = v & 7;
+    const int hy = (int)(((float)px + 0.5f) * inv_hc), hx = px - hy * hHC;
+    hlo[u] = v < hHR * hHC * 8 ? px * CP + cv * 8 : -1;
+    hyx[u] = (hy << 16) | hx;
+  }
+  Vec8<T> hv[NHV];
+  auto issue_halo = [&](int tile) {
+    const int b = tile / tiles_img, trem = tile - b * tiles_img;
+    const int iy0 = (trem / tilesX) * tTR - 1, ix0 = (trem % tilesX) * tTC - 1;
+#pragma unroll
+    for (int u = 0; u < NHV; ++u) {
+      const int iy = iy0 + (hyx[u] >> 16), ix = ix0 + (hyx[u] & 0xFFFF);
+      const bool ok = (hlo[u] >= 0) & (iy >= 0) & (iy < p.H) & (ix >= 0) & (ix < p.W);
+      BufLoad8<T>::load(hv[u], rs, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.srcCs[0] + (threadIdx.x & 7) * 8) * 2) : EY_OOB, 0);
+    }
+  };
+  // fragment bases of this lane: pixel slot q = wave * 64 + mt * 16 + r of the flattened tile
+  int bbase[MT], prow[MT], pcol[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int q = wave * 64 + mt * 16 + r;
+    const bool qv = q < tTR * tTC;
+    prow[mt] = qv ? (int)(((float)q + 0.5f) * inv_tc) : 0;
+    pcol[mt] = qv ? q - prow[mt] * tTC : 0;
+    bbase[mt] = (prow[mt] * hHC + pcol[mt]) * CP + 8 * g;
+    if (!qv) prow[mt] = 1 << 20;  // never stored
+  }
+  const T* wlane = wl + r * CP + 8 * g;
+  const int BNp = 16 * p.NTpack;
+  const int ch0 = (n_base / BNp) * BNp + g * 4 * p.NTpack + 4 * ((n_base % BNp) >> 4);
+
+  // Two accumulator sets alternate between tiles (FAST): the MFMAs of tile i write set i & 1 while the epilogue quarters read set
+  // (i - 1) & 1 -- both stay in the accumulator registers, a quarter pulls its 4 values out when it runs (no second VGPR copy of a
+  // whole tile: the arch-VGPR budget goes to the double-buffered operand fragments instead).
+  f32x4 acc[2][MT][NT];
+  // FAST epilogue state: bias of this lane's 4*NT channels, the output view as a range-checked buffer, the previous tile's per-block
+  // store offsets (out of range = dropped: pixels outside the map, and everything while there is no previous tile)
+  float bz[4 * NT];
+  unsigned yoff[MT];
+  unsigned oh[2 * NT];  // a block's 4*NT converted outputs, two halves per register
+  __amdgpu_buffer_rsrc_t ry = ey_rsrc(p.y, p.srcBytes[1]);
+  if constexpr (FAST) {
+#pragma unroll
+    for (int q = 0; q < NT; ++q) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + ch0 + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bz[4 * q + j] = bv[j];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) yoff[mt] = EY_OOB;
+  }
+  auto set_yoff = [&](int t) {
+    const int b = t / tiles_img, trem = t - b * tiles_img;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int oy = (trem / tilesX) * tTR + prow[mt], ox = (trem % tilesX) * tTC + pcol[mt];
+      yoff[mt] = (oy < p.Ho && ox < p.Wo) ? (unsigned)(((((long)b * p.Ho + oy) * p.Wo + ox) * p.yCs + ch0) * 2) : EY_OOB;
+    }
+  };
+  auto quarter = [&](const f32x4 (&src)[MT][NT], int mt, int q) {  // outputs 4q .. 4q+3 of block mt of a finished tile (conv_epilogue's arithmetic)
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = src[mt][q][j] + bz[4 * q + j];
+      v[j] = v[j] * ey_sigmoid(v[j]);
+    }
+    const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    const uint2 u = __builtin_bit_cast(uint2, h);
+    oh[2 * q] = u.x;
+    oh[2 * q + 1] = u.y;
+    if (q == NT - 1) {
+#pragma unroll
+      for (int c = 0; c < NT / 2; ++c) {
+        const u32x4 d = {oh[4 * c], oh[4 * c + 1], oh[4 * c + 2], oh[4 * c + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(d, ry, (int)yoff[mt], 16 * c, 0);
+      }
+    }
+  };
+  auto tile_body = [&](auto cur_c, int tile) {
+    constexpr int CUR = decltype(cur_c)::value;
+    ey_lds_barrier();  // every wave finished reading the previous tile's halo (first pass: the weights are staged)
+#pragma unroll
+    for (int u = 0; u < NHV; ++u)
+      if (hlo[u] >= 0) hv[u].store(hl + hlo[u]);
+    ey_lds_barrier();  // (LDS only: neither the halo prefetch below nor the epilogue stores are drained at a barrier)
+    if (tile + gridDim.x < ntiles) issue_halo(tile + gridDim.x);  // in flight during the K loop below
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[CUR][mt][nt] = (f32x4)0.f;
+    // 18 k-steps; the operand fragments of step k + 1 are read from LDS while the 16 MFMAs of step k are issued
+    Vec8<T> af[2][NT], bf[2][MT];
+    auto ld_step = [&](int k, Vec8<T> (&a)[NT], Vec8<T> (&bq)[MT]) {
+      const int tap = k >> 1, ks = k & 1;
+      const int toff = ((tap / 3) * hHC + tap % 3) * CP + ks * 32;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) a[nt].load(wlane + (tap * 16 * NT + nt * 16) * CP + ks * 32);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) bq[mt].load(hl + bbase[mt] + toff);
+    };
+    ld_step(0, af[0], bf[0]);
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      // step k + 1's fragments are requested HERE, a whole step (16 MFMAs = 256 cycles) before their first use: the scheduling barrier
+      // keeps the scheduler from sinking the reads to the MFMAs that consume them (it does, left alone, and every step then waits
+      // out an LDS round trip: 33 us -> see profiles/r03_c3s_c3p_vs_tile.txt)
+      if (k < 17) ld_step(k + 1, af[(k + 1) & 1], bf[(k + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[CUR][mt][nt] = mma16(af[k & 1][nt], bf[k & 1][mt], acc[CUR][mt][nt]);
+      if constexpr (FAST) {
+        if (k < MT * NT) quarter(acc[1 - CUR], k / NT, k % NT);  // one quarter-block of the previous tile's epilogue per k-step
+        // pinned issue order: every MFMA of the step with two epilogue VALU ops in its shadow
+#pragma unroll
+        for (int i = 0; i < MT * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FAST) {
+      set_yoff(tile);
+    } else {
+      const int b = tile / tiles_img, trem = tile - b * tiles_img;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int oy = (trem / tilesX) * tTR + prow[mt], ox = (trem % tilesX) * tTC + pcol[mt];
+        if (oy < p.Ho && ox < p.Wo) conv_epilogue<T, NT>(p, acc[CUR][mt], ((long)b * p.Ho + oy) * p.Wo + ox, b, oy, ox, ch0, 0);
+      }
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) issue_halo(tile);
+  int last = -1;  // accumulator set of the last finished tile (workgroup-uniform)
+  while (tile < ntiles) {
+    tile_body(std::integral_constant<int, 0>{}, tile);
+    last = 0;
+    tile += gridDim.x;
+    if (tile >= ntiles) break;
+    tile_body(std::integral_constant<int, 1>{}, tile);
+    last = 1;
+    tile += gridDim.x;
+  }
+  if constexpr (FAST) {  // the last tile's epilogue
+    if (last == 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) quarter(acc[0], mt, q);
+    } else if (last == 1) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int q = 0; q < NT; ++q) quarter(acc[1], mt, q);
+    }
+  }
+}
+
+// ================================================================================================================
 // 3x3 "stream" kernel (f16, one source, Cin = 64 * UPT, stride 1 or 2): weight-stationary like conv_ws_kernel, but shaped for the
 // K = 576 ... 2304 convs (backbone down-sampling layers 3/5/7/17/20, the Detect box towers) whose time the tile kernel above spends
 // outside the MFMA loop (halo staging and two barriers per 32-channel chunk, a prologue and an epilogue every workgroup reaches at
@@ -1811,6 +2026,71 @@ static int dispatch_c3r(ConvP p, int ngroup, hipStream_t st) {
   return 0;
 }
 
+// ---- persistent 3x3 tile kernel dispatch (f16, Cin = 64, stride 1, Cout a multiple of 64 or exactly 32 / 16)
+template <int NT>
+static int c3p_launch(ConvP p, hipStream_t st) {
+  // flattened tile: the (rows x cols) with <= 256 pixels and <= 340 halo pixels that wastes the fewest slots (as tile_launch)
+  int tr = 8, tc = 32;
+  {
+    double best = 0.0;
+    const int cands[8] = {16, 20, 24, 28, 32, 36, 40, p.Wo};
+    for (int i = 0; i < 8; ++i) {
+      const int c = cands[i];
+      if (c < 8 || c > 80) continue;
+      int rr = 256 / c;
+      while (rr > 1 && (rr + 2) * (c + 2) > 340) --rr;
+      if (rr < 1 || (rr + 2) * (c + 2) > 340) continue;
+      const long cov = (long)((p.Wo + c - 1) / c) * ((p.Ho + rr - 1) / rr) * 256;
+      const double eff = (double)p.Wo * p.Ho / (double)cov;
+      if (eff > best + 1e-9) { best = eff; tr = rr; tc = c; }
+    }
+  }
+  p.tTR = tr; p.tTC = tc;
+  const long tiles = (long)p.B * ((p.Wo + tc - 1) / tc) * ((p.Ho + tr - 1) / tr);
+  if (tiles >= (1L << 30)) return 0;
+  const int ny = conv_cout_pad(p.Cout) / (16 * NT);
+  const size_t lds = ((size_t)9 * 16 * NT + 340) * 80 * 2;
+  static bool reserved = false;
+  if (!reserved) {
+    if (hipFuncSetAttribute((const void*)conv3p_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3p_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return 0;
+    reserved = true;
+  }
+  long gx = 256 / ny;
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  // the interleaved epilogue: bias + SiLU only, whole 16-byte-aligned channel tiles, output view addressable with 32-bit offsets
+  const long ybytes = (((long)p.B * p.Ho * p.Wo - 1) * p.yCs + p.Cout) * 2L;
+  const bool fast = tune().c3p_fast && p.bias && p.act == EY_ACT_SILU && p.out_scale == 1.f && !p.res && !p.addz && p.vec_store == 2 && p.Cout % (16 * NT) == 0 &&
+                    ybytes < (1L << 31);
+  p.srcBytes[1] = fast ? (unsigned)ybytes : 0u;
+  const dim3 gg((unsigned)gx, (unsigned)ny, 1);
+  if (fast) hipLaunchKernelGGL((conv3p_kernel<NT, true>), gg, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv3p_kernel<NT, false>), gg, dim3(256), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(c3p): %s", hipGetErrorString(e_));
+  g_last_variant = 9000 + NT * 10 + (fast ? 1 : 0);
+  return 1;
+}
+template <typename T>
+static int dispatch_c3p(ConvP p, int ngroup, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) return 0;
+  else {
+    if (!tune().c3p || p.k != 3 || p.stride != 1 || p.nsrc != 1 || p.srcUp[0] || ngroup != 1 || p.srcC[0] != 64) return 0;
+    const int ntp = conv_nt(p.Cout);
+    if (ntp % 4 != 0 || conv_cout_pad(p.Cout) % 64) return 0;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    if (tune().c3p < 2 && M < tune().c3p_min_m) return 0;
+    const long npix = (long)p.B * p.H * p.W;
+    const long bytes = ((npix - 1) * p.srcCs[0] + p.srcC[0]) * 2L;
+    if (bytes >= (1L << 31) || (long)conv_cout_pad(p.Cout) * p.Kpad * 2L >= (1L << 31)) return 0;
+    p.srcBytes[0] = (unsigned)bytes;
+    p.NTpack = ntp;
+    return c3p_launch<4>(p, st);
+  }
+}
+
 // ---- 3x3 stream kernel dispatch (f16, Cin in {64, 128, 256}, one source, no groups)
 template <int NT, int MT, int UPT, int S, int NB>
 static int c3s_launch2(ConvP p, hipStream_t st) {
@@ -2119,6 +2399,8 @@ static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   if (cr != 0) return cr < 0 ? cr : EY_OK;
   const int cs = dispatch_c3s<T>(p, ngroup, st);
   if (cs != 0) return cs < 0 ? cs : EY_OK;
+  const int cp = dispatch_c3p<T>(p, ngroup, st);
+  if (cp != 0) return cp < 0 ? cp : EY_OK;
   const int tl = dispatch_tile<T>(p, ngroup, st);
   if (tl != 0) return tl < 0 ? tl : EY_OK;
   const int halo = dispatch_halo<T>(p, ngroup, st);

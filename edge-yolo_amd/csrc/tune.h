@@ -15,6 +15,9 @@ struct EyTune {
   long tile_s2_minc = 64;       // tile kernel for stride 2 only from this many input channels ...
   long tile_s2_minm = 40000;    // ... and this many output pixels (measured: below, the weight-stationary / halo kernels win)
   long grid_div = 1;            // persistent kernels: launch 1/grid_div of the resident slots
+  long c3p = 1;                 // persistent weight-resident 3x3 tile kernel for Cin = 64, stride 1 (0 = off, 2 = every shape it takes)
+  long c3p_min_m = 40000;       // ... from this many output pixels
+  long c3p_fast = 1;            // ... deferred + interleaved bias/SiLU epilogue where the conv allows it (0 = generic epilogue after the K loop)
   long c3s = 1;                 // 3x3 stream kernel (weights LDS-resident, pixels straight from L2) for Cin in {64, 128, 256} (0 = off)
   long c3s_mt4_m = 100000;      // ... 4 pixel blocks per wave from this many output pixels (else 2)
   long c3s_min_work = 40000;    // ... only for stride-2 convs with at least this many (output pixels x channel tiles); c3s = 2: everywhere

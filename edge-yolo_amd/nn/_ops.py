@@ -180,7 +180,9 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         with rec:
             L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
             lv = L.lib().ey_conv_last_variant()
-            if lv >= 8000:
+            if lv >= 9000:
+                rec.kernel = f"conv3p_kernel<{lv % 1000 // 10}>"
+            elif lv >= 8000:
                 rec.kernel = f"conv3s_kernel<{lv % 1000 // 100},{lv % 100 // 10},{lv % 10}>"
             elif lv >= 7000:
                 rec.kernel = f"conv3r_kernel<{lv % 1000 // 10},{lv % 10}>"

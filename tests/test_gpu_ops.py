@@ -375,3 +375,52 @@ def test_conv3_stream_kernel_views_residual_act(M):
     want = x[:, 64:].half().float() + om.conv(sd, "c3sv", x[:, 64:].half().float(), 3, 1, act=False)
     check(buf[:, 64:128], want, torch.float16)
     assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 128:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("c2,hw,B", [(64, 80, 3), (64, 40, 6), (64, 20, 32), (128, 40, 5), (64, 21, 7), (64, 9, 2), (192, 24, 3)])
+def test_conv3_persistent_tile_kernel(M, c2, hw, B):
+    """conv3p_kernel (Cin = 64, stride 1: weights LDS-resident for the life of a persistent workgroup, all-channel halo, epilogue of tile i
+    deferred into the K loop of tile i + 1) at the Detect box-tower shapes, odd maps (partial tiles, out-of-image halo) and several channel
+    tiles: against the fp32 oracle and against the tile kernel it replaces (tunable c3p = 0)."""
+    from edge_yolo_amd import _lib as L
+    m = M.Conv(64, c2, 3, 1)
+    sd = load_synth(m, "c3p")
+    x = synth.synth_images(B, hw, hw + (3 if hw in (21, 9) else 0), seed=7, c=64) - 0.5
+    xd = x.to("cuda", torch.float16)
+    m = to_dev(m, torch.float16)
+    m.fuse_bn()
+    lib = L.lib()
+    try:
+        L.check(lib.ey_tune_set(b"c3p", 2), "tune")
+        got = m(xd)
+        assert lib.ey_conv_last_variant() // 1000 == 9, f"persistent tile kernel not dispatched (variant {lib.ey_conv_last_variant()})"
+        L.check(lib.ey_tune_set(b"c3p", 0), "tune")
+        old = m(xd)
+        assert lib.ey_conv_last_variant() // 1000 != 9
+    finally:
+        L.check(lib.ey_tune_set(b"c3p", 1), "tune")
+    torch.cuda.synchronize()
+    assert float((got.float() - old.float()).abs().max()) <= 2e-3 * max(1.0, float(old.float().abs().max()))
+    check(got, om.conv(sd, "c3p", x.half().float(), 3, 1), torch.float16, what=f"Conv 64->{c2} k3s1 {hw}x{hw}")
+
+
+def test_conv3_persistent_tile_kernel_views_residual(M):
+    """conv3p with out= into a channel slice, a channel-sliced input, residual add, no activation (the deferred epilogue's operands)."""
+    from edge_yolo_amd import _lib as L
+    m = M.Conv(64, 64, 3, 1, act=False)
+    sd = load_synth(m, "c3pv")
+    x = synth.synth_images(3, 26, 30, seed=8, c=128) - 0.5
+    xd = x.to("cuda", torch.float16)
+    m = to_dev(m, torch.float16)
+    buf = L.empty_nhwc(3, 192, 26, 30, torch.float16, "cuda")
+    buf.zero_()
+    xin = L.as_nhwc(xd)[:, 64:]
+    L.check(L.lib().ey_tune_set(b"c3p", 2), "tune")
+    try:
+        m(xin, out=buf[:, 64:128], res=xin)
+        assert L.lib().ey_conv_last_variant() // 1000 == 9
+    finally:
+        L.check(L.lib().ey_tune_set(b"c3p", 1), "tune")
+    want = x[:, 64:].half().float() + om.conv(sd, "c3pv", x[:, 64:].half().float(), 3, 1, act=False)
+    check(buf[:, 64:128], want, torch.float16)
+    assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 128:].abs().max()) == 0
