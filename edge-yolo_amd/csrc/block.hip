@@ -555,7 +555,7 @@ extern "C" int ey_block_compile(const ey_block_stage* st, int nstages, void* out
         EY_CHECK((s.src_g * 2) % 16 == 0 && (s.y_g * 2) % 16 == 0, "block stage %d: group strides", i);
         int Cin = 0;
         for (int j = 0; j < s.nsrc; ++j) Cin += s.src_C[j];
-        s.kpad = ey_conv_kpad(s.k * s.k * Cin);
+        s.kpad = ey_conv_kpad(s.k * s.k * Cin, 2);
         s.nt_pack = ey_conv_pack_nt(s.Cout);
         s.zsy = s.has_addz ? (float)s.addz_H / (float)s.Ho : 0.f;
         s.zsx = s.has_addz ? (float)s.addz_W / (float)s.Wo : 0.f;

@@ -25,10 +25,19 @@ int ey_set_error(int code, const char* fmt, ...);
     if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "%s: %s", name, hipGetErrorString(e_)); \
   } while (0)
 
-// Row length (elements) of a packed conv weight row holding K = k*k*Cin values: +32 zero slack (masked tail lanes may read
-// past the row) and an ODD number of 16-byte f16 units, so the same stride is bank-conflict-free in LDS and a weight
-// tile is one contiguous block in global memory (staging = flat copy, no per-vector row arithmetic).
-static inline int ey_conv_kpad(int K) { const int kp = K + 32; return ((kp >> 3) & 1) ? kp : kp + 8; }
+// Row length (elements) of a packed conv weight row holding K = k*k*Cin values: +32 zero slack (masked tail lanes may read past the
+// row), rounded so that the same pitch is bank-conflict-free for the MFMA fragment reads from LDS (lane (r, g) reads row r at +16g
+// bytes with ds_read_b128, which the hardware serves in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32): f16 rows are
+// 2 (mod 4) 16-byte units long -- an ODD number of units, the rule of rounds 1-2, is a 2-way conflict in every group
+// (SQ_LDS_BANK_CONFLICT = 54 % of conv3_tile_kernel's LDS cycles; 0 at a pitch of 10 units, profiles/r03_conv3_kernels.txt) --
+// f32 rows an odd number of 8-element (32-byte) units, i.e. also 2 (mod 4) 16-byte units.  A weight tile is one contiguous block in
+// global memory (staging = flat copy, no per-vector row arithmetic).
+static inline int ey_conv_kpad(int K, int es) {
+  int units = (K + 32) >> 3;
+  if (es == 2) while ((units & 3) != 2) ++units;
+  else if (!(units & 1)) ++units;
+  return units * 8;
+}
 static inline bool ey_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 static inline int ey_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -1712,18 +1712,18 @@ static int conv_nt(int Cout) {  // channels per block tile / 16
   return 8;
 }
 static int conv_cout_pad(int Cout) { int bn = 16 * conv_nt(Cout); return (Cout + bn - 1) / bn * bn; }
-static int conv_kpad(int Cin, int k) { return ey_conv_kpad(k * k * Cin); }
+static int conv_kpad(int Cin, int k, int es) { return ey_conv_kpad(k * k * Cin, es); }
 
 #if EY_CONV_PART == 16
 extern "C" size_t ey_conv_packed_bytes(int dtype, int Cout, int Cin, int k) {
-  return (size_t)conv_cout_pad(Cout) * conv_kpad(Cin, k) * (dtype == EY_F16 ? 2 : 4);
+  return (size_t)conv_cout_pad(Cout) * conv_kpad(Cin, k, dtype == EY_F16 ? 2 : 4) * (dtype == EY_F16 ? 2 : 4);
 }
 
 extern "C" int ey_conv_pack_weight(int dtype, int Cout, int Cin, int k, const float* w, void* out, size_t out_bytes) {
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "pack: bad dtype %d", dtype);
   EY_CHECK(Cout > 0 && Cin > 0 && (k == 1 || k == 3), "pack: Cout=%d Cin=%d k=%d", Cout, Cin, k);
   EY_CHECK(out_bytes >= ey_conv_packed_bytes(dtype, Cout, Cin, k), "pack: output buffer too small");
-  const int NT = conv_nt(Cout), BN = 16 * NT, Kp = conv_kpad(Cin, k), rows = conv_cout_pad(Cout);
+  const int NT = conv_nt(Cout), BN = 16 * NT, Kp = conv_kpad(Cin, k, dtype == EY_F16 ? 2 : 4), rows = conv_cout_pad(Cout);
   for (int row = 0; row < rows; ++row) {
     // MFMA row rho = 4g+j of n-block nt inside block tile nb  <->  channel nb*BN + g*4NT + 4nt + j
     const int nb = row / BN, within = row % BN, nt = within / 16, rho = within % 16, g = rho / 4, j = rho % 4;
@@ -1782,7 +1782,7 @@ thread_local int g_last_variant = 0;
 extern thread_local int g_last_variant;
 #endif
 // ---- weight-stationary dispatch
-static int ws_ls(int Kpad) { return Kpad; }  // conv_kpad() already makes the row an odd number of 16-byte (f16) units
+static int ws_ls(int Kpad) { return Kpad; }  // conv_kpad() already makes the row pitch conflict-free for the LDS fragment reads
 static const int WS_NT[5] = {8, 5, 4, 2, 1};
 // largest NT (<= the packing NT, dividing it into whole 16-row blocks) whose weight tile fits `budget` bytes of LDS
 static int ws_pick_nt(int Cout, int Kpad, int es, size_t budget) {
@@ -2457,7 +2457,7 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   p.out_scale = d->out_scale; p.addz = d->addz; p.addzCs = d->addz_cstride; p.Hz = d->addz_H; p.Wz = d->addz_W;
   p.zsy = d->addz ? (float)d->addz_H / (float)d->Ho : 0.f; p.zsx = d->addz ? (float)d->addz_W / (float)d->Wo : 0.f; p.srcG = d->src_gstride; p.yG = d->y_gstride;
   p.wG = d->w_gstride; p.wGmax = d->w_gmax > 0 ? d->w_gmax : 0;
-  p.Kpad = conv_kpad(Cin, d->k);
+  p.Kpad = conv_kpad(Cin, d->k, es);
   p.nchunks = 0;
   for (int s2 = 0; s2 < d->nsrc; ++s2) p.nchunks += (d->src_C[s2] + CONV_CH - 1) / CONV_CH;
   p.nchunks *= d->k * d->k;
@@ -2523,9 +2523,9 @@ extern "C" int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmi
   ConvP p;
   p.B = B; p.H = H; p.W = W; p.Ho = H; p.Wo = W; p.Cout = Cmid; p.act = act1; p.nsrc = 1;
   p.src[0] = x; p.srcC[0] = Cin; p.srcCs[0] = x_cstride; p.srcBytes[0] = (unsigned)bytes;
-  p.w = w1_packed; p.bias = b1; p.Kpad = conv_kpad(Cin, 1); p.ntile = (M + 15) / 16;
+  p.w = w1_packed; p.bias = b1; p.Kpad = conv_kpad(Cin, 1, 2); p.ntile = (M + 15) / 16;
   ChainP q;
-  q.w2 = w2_packed; q.b2 = b2; q.act2 = act2; q.Cout2 = Cout; q.Kpad2 = conv_kpad(ey_conv_chain_klen(Cmid), 1); q.y2 = y; q.y2Cs = y_cstride;
+  q.w2 = w2_packed; q.b2 = b2; q.act2 = act2; q.Cout2 = Cout; q.Kpad2 = conv_kpad(ey_conv_chain_klen(Cmid), 1, 2); q.y2 = y; q.y2Cs = y_cstride;
   return wide ? pw2_launch<5, 3, 5>(p, q, (hipStream_t)stream) : pw2_launch<4, 2, 1>(p, q, (hipStream_t)stream);
 }
 
@@ -2533,7 +2533,7 @@ extern "C" int ey_conv_pw_chain(int dtype, int B, int H, int W, int Cin, int Cmi
 // kind 3 = conv_small_kernel<T,NT,BATCH> (last digit = BATCH), 2 = conv3_halo_kernel<T,NT,stride>,
 // 1 = conv_ws_kernel<T,NT,MT,k>, 0 = conv_igemm_kernel<T,NT,MT>.
 extern "C" int ey_conv_variant(int dtype, int Cout, int Cin, int k, int stride, int plain_single_source, long M, int ngroup) {
-  const int es = dtype == EY_F16 ? 2 : 4, Kpad = conv_kpad(Cin, k);
+  const int es = dtype == EY_F16 ? 2 : 4, Kpad = conv_kpad(Cin, k, es);
   if (small_ok(Cout, Kpad, k, M, es)) return 3000 + small_pick_nt(Cout, es) * 10 + (es == 2 ? 8 : 4);
   if (k == 3 && plain_single_source && Cin <= 64 && Cin >= 48) {
     ConvP p;

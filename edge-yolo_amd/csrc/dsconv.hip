@@ -670,7 +670,7 @@ extern "C" int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, i
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
   p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)((((long)B * H * W - 1) * x_cstride + Cin) * es);
   p.wdw = w_dw_kkc; p.dwbias = dw_bias; p.dwact = dw_act; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
-  p.Kpad = ey_conv_kpad(Cin);
+  p.Kpad = ey_conv_kpad(Cin, es);
   p.NTpack = ds_conv_nt(Cout);
   p.vec_store = 1;
   hipStream_t st = (hipStream_t)stream;
@@ -702,7 +702,7 @@ extern "C" int ey_dsconv(int dtype, int B, int H, int W, int Cin, int Cout, int 
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.act = act;
   p.x = x; p.xCs = x_cstride; p.xBytes = (unsigned)xbytes;
   p.wdw = w_dw_kkc; p.dwbias = dw_bias; p.dwact = dw_act; p.wpw = w_pw_packed; p.bias = bias; p.y = y; p.yCs = y_cstride; p.res = res; p.resCs = res_cstride;
-  p.Kpad = ey_conv_kpad(Cin);
+  p.Kpad = ey_conv_kpad(Cin, es);
   p.NTpack = ds_conv_nt(Cout);
   p.tilesX = (W + DS_TW - 1) / DS_TW; p.tilesY = (H + DS_TH - 1) / DS_TH;
   p.ntile = (long)B * p.tilesX * p.tilesY;

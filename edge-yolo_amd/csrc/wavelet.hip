@@ -22,7 +22,11 @@ struct WzP {
 };
 
 __host__ __device__ constexpr int wz_nt(int cout) { return cout <= 16 ? 1 : cout <= 32 ? 2 : cout <= 64 ? 4 : cout <= 80 ? 5 : 8; }
-__host__ __device__ constexpr int wz_kpad(int K) { return (((K + 32) >> 3) & 1) ? K + 32 : K + 40; }
+__host__ __device__ constexpr int wz_kpad(int K) {  // == ey_conv_kpad(K, 2): 2 (mod 4) 16-byte units
+  int units = (K + 32) >> 3;
+  while ((units & 3) != 2) ++units;
+  return units * 8;
+}
 
 // NS: the output-channel blocks of both contractions are split over NS wave groups (4 x NS waves per workgroup): wide channel counts sit
 // on small maps (c = 128 at 20x20: 3 tiles per image), where four waves walking 500 dependent MFMA steps each would be pure latency.

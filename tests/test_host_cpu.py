@@ -95,7 +95,7 @@ def test_weight_packing_layout(cout, cin, k):
     buf = torch.zeros(nbytes, dtype=torch.uint8)
     assert L.lib().ey_conv_pack_weight(L.F32, cout, cin, k, w.data_ptr(), buf.data_ptr(), nbytes) == 0
     kp = k * k * cin + 32
-    kp += 0 if (kp >> 3) & 1 else 8  # rows are an odd number of 16-byte f16 units (LDS-stride compatible, ey_conv_kpad)
+    kp += 0 if (kp >> 3) & 1 else 8  # f32 rows: an odd number of 8-element units = 2 (mod 4) 16-byte units (conflict-free LDS pitch, ey_conv_kpad)
     p = buf.view(torch.float32).view(-1, kp)
     nt = L.lib().ey_conv_pack_nt(cout)
     bn = 16 * nt
