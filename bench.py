@@ -286,12 +286,13 @@ def rehearse_cpu(a, world, rank):
                         on_block=lambda k: seen.extend(float(r[0, 0]) for r in gather.results(k)))
     if gather is not None:  # every rank holds every image's rows, in global order (warm-up blocks included)
         assert seen == [float(v) for v in range((a.warmup + a.steps) * world * B)], seen[:8]
-    if rank == 0:
-        print(json.dumps({"metric": "REHEARSAL (control flow only: gloo backend, stub step, no device work) -- not a measurement", "value": 0.0,
-                          "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-                          "data": "none", "rows_checked": len(seen)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        return {"metric": "REHEARSAL (control flow only: gloo backend, stub step, no device work) -- not a measurement", "value": 0.0,
+                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+                "data": "none", "rows_checked": len(seen)}
+    return None
 
 
 def make_pipeline(model, images, cuts, head_nms, conf, iou, max_det, streams=None, nms_stage=False):
@@ -322,11 +323,33 @@ def make_pipeline(model, images, cuts, head_nms, conf, iou, max_det, streams=Non
     return pipe
 
 
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 -> 2 for the duration: the collective backend prints its banner ("RCCL version : ...") to stdout when the first
+    communicator is created, and stdout must carry exactly ONE line, the JSON."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
     a = parse(argv)
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a, argv))
+    with stdout_to_stderr():
+        out = run(a)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def run(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -455,10 +478,9 @@ def main(argv=None):
         out["predict_batches_u8"] = api_throughput(a.model, sd, a.nc, a.batch, a.imgsz, a.dtype == "f16", min(a.steps, 40), 8, conf, iou, max_det, dev, u8=True)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.model, sd, a.imgsz, a.cpu_images, conf, iou, nc=a.nc)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if use_gather:
         dist.destroy_process_group()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

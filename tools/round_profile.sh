@@ -18,4 +18,7 @@ timeout -k 10 300 python $R/bench.py --model yolo11n.yaml --no-cpu-baseline --no
 timeout -k 10 300 python $R/bench.py --imgsz 1280 --batch 8 --no-cpu-baseline --no-api > $O/bench_${T}_c5_1280_b8.json 2>> $O/bench_$T.err
 timeout -k 10 300 python $R/bench.py --nc 10 --no-cpu-baseline --no-api > $O/bench_${T}_nc10.json 2>> $O/bench_$T.err
 timeout -k 10 300 python $R/bench.py --no-pipeline --no-cpu-baseline --no-api --no-roofline > $O/bench_${T}_single_graph.json 2>> $O/bench_$T.err
-for f in c2_yolo11n c5_1280_b8 nc10 single_graph; do python3 -c "import json,sys; d=json.load(open('$O/bench_${T}_$f.json')); print('$f', d['value'], d['ms_per_step'])"; done
+timeout -k 10 300 python $R/bench.py --regime sparse --no-cpu-baseline --no-api > $O/bench_${T}_sparse.json 2>> $O/bench_$T.err
+timeout -k 10 300 python $R/bench.py --regime sparse --cls-bias-shift 5 --no-cpu-baseline --no-api --no-roofline > $O/bench_${T}_sparse_shift5.json 2>> $O/bench_$T.err
+timeout -k 10 300 python $R/bench.py --force-gather --no-cpu-baseline --no-api --no-roofline > $O/bench_${T}_force_gather.json 2>> $O/bench_$T.err
+for f in c2_yolo11n c5_1280_b8 nc10 single_graph sparse sparse_shift5 force_gather; do python3 -c "import json,sys; d=json.load(open('$O/bench_${T}_$f.json')); print('$f', d['value'], d['ms_per_step'])"; done

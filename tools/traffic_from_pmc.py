@@ -30,6 +30,12 @@ def label_of(name):
     m = re.search(r"conv3_tile_kernelIDF16_Li(\d+)ELi(\d+)E", name)
     if m:
         return f"conv3_tile_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv3s_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"conv3s_kernel<(\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        return f"conv3s_kernel<{m[1]},{m[2]},{m[4]}>"
+    m = re.search(r"conv3p_kernelILi(\d+)E", name) or re.search(r"conv3p_kernel<(\d+)", name)
+    if m:
+        return f"conv3p_kernel<{m[1]}>"
     m = re.search(r"conv3r_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"conv3r_kernel<(\d+), (\d+)>", name)
     if m:
         return f"conv3r_kernel<{m[1]},{m[2]}>"
@@ -56,6 +62,9 @@ def label_of(name):
     if "dwconv3_strip" in name:
         return "dwconv_kernel<3>"
     for k in ("stem_kernel", "dwt_kernel", "head_decode_kernel", "linattn_kernel", "sppf_kernel", "copy_kernel", "softattn_kernel"):
+        if k in name:
+            return k
+    for k in ("nf_select_kernel", "nf_mask_kernel", "nf_resolve_kernel", "scale_img_kernel", "tta_merge_kernel"):
         if k in name:
             return k
     if "nms_select" in name:
@@ -94,6 +103,6 @@ if __name__ == "__main__":
         out[lab] = {"launches_profiled": nf, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                     "hbm_bytes_per_launch": round(fetch + write), "fetch_kb_raw_avg": round(kf / max(nf, 1), 1)}
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py --no-pipeline; FETCH_SIZE x 2 = 128-byte lines fetched "
-                         "(calibrated for 2/4/8/16 B per lane coalesced reads: profiles/r02_fetch_size_calibration.txt)",
+                         "(calibrated for 2/4/8/16 B per lane coalesced reads: profiles/r02_fetch_size_calibration.txt; nf_select / nf_mask / nf_resolve are the three kernels of the `nms_fast(...)` operator row of bench.py's roofline table)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     print(f"{len(out)} kernels -> {sys.argv[3]}")
