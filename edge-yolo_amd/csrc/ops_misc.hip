@@ -452,49 +452,67 @@ extern "C" int ey_dwt_haar(int dtype, int B, int H, int W, int C, const void* x,
 }
 
 // ============================================================================ SPPF: three chained 5x5 max pools
-// block = one image x one 8-channel vector; the whole (H x W x 8ch) plane lives in LDS; separable max (row pass,
-// column pass) applied three times, exactly the reference's chain (padding acts as -inf).
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_kernel(int H, int W, int C, const T* __restrict__ x, int xCs, T* __restrict__ y1, T* __restrict__ y2,
-                                                   T* __restrict__ y3, int yCs) {
+// block = one image x CV consecutive 8-channel vectors; the whole (H x W x 8*CV ch) plane lives in LDS; separable max (row pass,
+// column pass) applied three times, exactly the reference's chain (padding acts as -inf).  CV = 8 for f16 at 20x20 (64 channels =
+// one 128-byte line per pixel: every line of x is fetched by exactly one workgroup and every output line is written whole; the first
+// version, CV = 1, had 16 workgroups pull the same lines for their own 16-byte slices: 3.5x the algorithmic bytes at the L2's memory
+// side, profiles/r02_pmc_traffic.json); smaller CV when the plane would not fit LDS.
+template <typename T, int CV>
+__global__ __launch_bounds__(1024) void sppf_kernel(int H, int W, int C, const T* __restrict__ x, int xCs, T* __restrict__ y1, T* __restrict__ y2,
+                                                    T* __restrict__ y3, int yCs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   Vec8<T>* A = reinterpret_cast<Vec8<T>*>(smem);
-  Vec8<T>* Bf = A + H * W;
-  const int cv = C >> 3;
-  const int b = blockIdx.x / cv, c8 = (blockIdx.x % cv) * 8;
+  Vec8<T>* Bf = A + H * W * CV;
+  const int groups = C / (8 * CV);
+  const int b = blockIdx.x / groups, c0 = (blockIdx.x % groups) * 8 * CV;
   const long base = (long)b * H * W;
-  for (int i = threadIdx.x; i < H * W; i += blockDim.x) A[i].load(x + (base + i) * xCs + c8);
+  const int n = H * W * CV;  // element i = pixel i / CV, vector i % CV (consecutive threads: consecutive 16-byte pieces of a pixel's line)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) A[i].load(x + (base + i / CV) * xCs + c0 + (i % CV) * 8);
   __syncthreads();
   T* outs[3] = {y1, y2, y3};
   for (int pass = 0; pass < 3; ++pass) {
-    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {  // rows
-      const int yy = i / W, xx = i - yy * W;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {  // rows
+      const int px = i / CV, yy = px / W, xx = px - yy * W;
       Vec8<T> mx = A[i];
       for (int dx = -2; dx <= 2; ++dx) {
         const int x2 = xx + dx;
         if (dx == 0 || x2 < 0 || x2 >= W) continue;
-        const Vec8<T>& o = A[yy * W + x2];
+        const Vec8<T>& o = A[i + dx * CV];
 #pragma unroll
         for (int k = 0; k < 8; ++k) mx.set(k, fmaxf(mx.get(k), o.get(k)));
       }
       Bf[i] = mx;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {  // columns
-      const int yy = i / W, xx = i - yy * W;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {  // columns
+      const int px = i / CV, yy = px / W;
       Vec8<T> mx = Bf[i];
       for (int dy = -2; dy <= 2; ++dy) {
         const int y2 = yy + dy;
         if (dy == 0 || y2 < 0 || y2 >= H) continue;
-        const Vec8<T>& o = Bf[y2 * W + xx];
+        const Vec8<T>& o = Bf[i + dy * W * CV];
 #pragma unroll
         for (int k = 0; k < 8; ++k) mx.set(k, fmaxf(mx.get(k), o.get(k)));
       }
-      mx.store(outs[pass] + (base + i) * yCs + c8);
+      mx.store(outs[pass] + (base + px) * yCs + c0 + (i % CV) * 8);
       A[i] = mx;  // only element i of A is touched by this thread: no hazard with the column reads of Bf
     }
     __syncthreads();
   }
+}
+
+template <typename T, int CV>
+static int sppf_launch(int B, int H, int W, int C, const void* x, int xCs, void* y1, void* y2, void* y3, int yCs, size_t lds, hipStream_t st) {
+  static size_t reserved = 0;
+  if (lds > 64 * 1024 && lds > reserved) {
+    if (hipFuncSetAttribute((const void*)sppf_kernel<T, CV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "sppf: cannot reserve %zu B of LDS", lds);
+    reserved = lds;
+  }
+  const int n = H * W * CV;
+  const int threads = n >= 1024 ? 1024 : n >= 512 ? 512 : 256;
+  hipLaunchKernelGGL((sppf_kernel<T, CV>), dim3(B * (C / (8 * CV))), dim3(threads), lds, st, H, W, C, (const T*)x, xCs, (T*)y1, (T*)y2, (T*)y3, yCs);
+  return EY_OK;
 }
 
 extern "C" int ey_sppf_pool(int dtype, int B, int H, int W, int C, const void* x, int x_cstride, void* y1, void* y2, void* y3, int y_cstride,
@@ -503,19 +521,24 @@ extern "C" int ey_sppf_pool(int dtype, int B, int H, int W, int C, const void* x
   EY_CHECK(dtype == EY_F16 || dtype == EY_F32, "sppf: bad dtype");
   EY_CHECK(C > 0 && C % 8 == 0, "sppf: C=%d must be a multiple of 8", C);
   const int es = dtype == EY_F16 ? 2 : 4;
-  const size_t lds = (size_t)H * W * 8 * es * 2;
-  EY_CHECK(lds <= 160 * 1024, "sppf: %dx%d plane does not fit LDS (%zu B)", H, W, lds);
+  EY_CHECK((size_t)H * W * 8 * es * 2 <= 160 * 1024, "sppf: %dx%d plane does not fit LDS", H, W);
   EY_CHECK((x_cstride * es) % 16 == 0 && (y_cstride * es) % 16 == 0 && ey_aligned(x, 16) && ey_aligned(y1, 16) && ey_aligned(y2, 16) && ey_aligned(y3, 16),
            "sppf: views must be 16-byte aligned");
-  dim3 grid(B * (C / 8));
+  // widest channel group (whole 128-byte lines where possible) whose two planes fit LDS and that divides C
+  int cv = 128 / (8 * es);  // vectors per 128-byte line: 8 (f16) / 4 (f32)
+  while (cv > 1 && (C % (8 * cv) || (size_t)H * W * cv * 8 * es * 2 > 150 * 1024)) cv >>= 1;
+  // ... but keep at least ~128 workgroups in flight: one CU stores its three output planes at a few bytes per clock, so 64 workgroups of
+  // whole lines (23 us) lose to 128 of half lines (measured: profiles/r03_sppf_groups.txt)
+  while (cv > 1 && (long)B * (C / (8 * cv)) < tune().sppf_min_wg) cv >>= 1;
+  if (tune().sppf_cv > 0 && tune().sppf_cv <= cv) cv = (int)tune().sppf_cv;
+  const size_t lds = (size_t)H * W * cv * 8 * es * 2;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EY_F16) {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)sppf_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ey_set_error(EY_ELAUNCH, "cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(sppf_kernel<f16>, grid, dim3(256), lds, st, H, W, C, (const f16*)x, x_cstride, (f16*)y1, (f16*)y2, (f16*)y3, y_cstride);
-  } else {
-    if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)sppf_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ey_set_error(EY_ELAUNCH, "cannot reserve %zu B of LDS", lds);
-    hipLaunchKernelGGL(sppf_kernel<float>, grid, dim3(256), lds, st, H, W, C, (const float*)x, x_cstride, (float*)y1, (float*)y2, (float*)y3, y_cstride);
-  }
+  int rc;
+#define EY_SPPF(TT, CVV) rc = sppf_launch<TT, CVV>(B, H, W, C, x, x_cstride, y1, y2, y3, y_cstride, lds, st)
+  if (dtype == EY_F16) { if (cv == 8) EY_SPPF(f16, 8); else if (cv == 4) EY_SPPF(f16, 4); else if (cv == 2) EY_SPPF(f16, 2); else EY_SPPF(f16, 1); }
+  else { if (cv == 4) EY_SPPF(float, 4); else if (cv == 2) EY_SPPF(float, 2); else EY_SPPF(float, 1); }
+#undef EY_SPPF
+  if (rc != EY_OK) return rc;
   EY_LAUNCH_CHECK("ey_sppf_pool");
   return EY_OK;
 }

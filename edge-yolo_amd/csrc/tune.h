@@ -38,6 +38,8 @@ struct EyTune {
   long stem_mfma = 1;           // MFMA stem kernel (0 = VALU stem)
   long linattn_mfma = 1;        // MFMA linear-attention kernel (0 = fp32 VALU kernel)
   long softattn_mfma = 1;       // MFMA softmax-attention kernel (0 = fp32 VALU kernel)
+  long sppf_min_wg = 128;       // SPPF pooling: shrink the channel group until at least this many workgroups are launched
+  long sppf_cv = 0;             // ... developer knob: force 8-channel vectors per workgroup (1, 2, 4, 8); 0 = the rule
   long nms_mask_wg = 0;         // nf_mask: workgroups per image (0 = the measured default)
   long nms_fast_k = 2048;       // predict-mode NMS: the three-kernel fast path over the best K candidates per image (<= 2048; 0 = general kernel only)
 };

@@ -167,6 +167,17 @@ def test_sppf(M, dtype, h, w):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("c1,h,w", [(256, 20, 20), (80, 13, 9), (128, 40, 40), (48, 7, 21)])
+def test_sppf_channel_groups(M, dtype, c1, h, w):
+    """SPPF pooling at the network's own shape (256 ch, 20x20: whole 128-byte lines per workgroup), at channel counts that only allow
+    narrower groups (c_ = 40, 24) and on a 40x40 plane (1280x1280 inputs: the group shrinks until two planes fit LDS)."""
+    m = M.SPPF(c1, c1, 5)
+    sd = load_synth(m, "sppfg")
+    x, xd = _x(3, c1, h, w, dtype, seed=4)
+    check(to_dev(m, dtype)(xd), om.sppf(sd, "sppfg", x), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("linear", [True, False])
 @pytest.mark.parametrize("h,w", [(4, 4), (20, 20)])
 def test_c2psa(M, dtype, linear, h, w):
