@@ -54,9 +54,6 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* s_box = reinterpret_cast<T*>(smem);           // [HD_ANCH][boxLs]  (scalar path only: boxLs == 0 on the vector path)
   T* s_cls = s_box + HD_ANCH * boxLs;              // [HD_ANCH][clsLs]
-  float* s_w1 = reinterpret_cast<float*>(s_cls + HD_ANCH * clsLs);  // [hid][20] quality FC1 (+ b1[hid], w2[hid] behind it)
-  float* s_b1 = s_w1 + hid * 20;
-  float* s_w2 = s_b1 + hid;
   const int HW = H * W;
   const long total = (long)B * HW;
   const long idx0 = (long)blk * HD_ANCH;
@@ -74,10 +71,6 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
   } else {
     for (int v = tid; v < nrow * 64; v += HD_ANCH) { const int row = v >> 6, c = v & 63; s_box[row * boxLs + c] = box[(idx0 + row) * boxCs + c]; }
     for (int v = tid; v < nrow * nc; v += HD_ANCH) { const int row = v / nc, c = v - row * nc; s_cls[row * clsLs + c] = cls[(idx0 + row) * clsCs + c]; }
-  }
-  if (w1) {  // the quality-head weights are read by every thread: LDS broadcast instead of dependent scalar loads
-    for (int v = tid; v < hid * 20; v += HD_ANCH) s_w1[v] = w1[v];
-    for (int v = tid; v < hid; v += HD_ANCH) { s_b1[v] = b1[v]; s_w2[v] = w2[v]; }
   }
   __syncthreads();
   if (tid >= nrow) return;
@@ -130,17 +123,23 @@ __global__ __launch_bounds__(HD_ANCH) void head_decode_kernel(int B, HdLevels lv
     f32x2 st2[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) st2[i] = f32x2{stat[2 * i], stat[2 * i + 1]};
+    // The weights are wave-uniform: read straight from global memory with uniform addresses they arrive by SCALAR loads (s_load_dwordx4 /
+    // x8 into SGPRs, the FMAs take them as scalar operands) -- no LDS broadcast read per 4 multiply-adds (320 ds_read_b128 per wave
+    // before, the kernel's bound).  Same operands in the same order: bit-identical.
+    const float* __restrict__ gw1 = w1;
+    const float* __restrict__ gb1 = b1;
+    const float* __restrict__ gw2 = w2;
 #pragma unroll 4
     for (int j = 0; j < hid; ++j) {
-      const f32x4* wr = reinterpret_cast<const f32x4*>(s_w1 + j * 20);
-      f32x2 h2 = {s_b1[j], 0.f};
+      const f32x4* wr = reinterpret_cast<const f32x4*>(gw1 + j * 20);
+      f32x2 h2 = {gb1[j], 0.f};
 #pragma unroll
       for (int i4 = 0; i4 < 5; ++i4) {
         const f32x4 w4 = wr[i4];
         h2 = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, st2[2 * i4], h2);
         h2 = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, st2[2 * i4 + 1], h2);
       }
-      o = __builtin_fmaf(s_w2[j], fmaxf(h2[0] + h2[1], 0.f), o);
+      o = __builtin_fmaf(gw2[j], fmaxf(h2[0] + h2[1], 0.f), o);
     }
     q = fminf(fmaxf(ey_sigmoid(o), 1e-6f), 1.f - 1e-6f);
   }
@@ -235,7 +234,7 @@ static int head_decode_impl(int dtype, int B, int nlevels, const int* H, const i
   lv.blk0[HD_MAXL] = (int)nblk;
   EY_CHECK(nblk < (1L << 31), "head_decode: too many anchors");
   const int boxLs = vec ? 0 : hd_pad(64, es), clsLs = hd_pad(nc, es);
-  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es + (quality ? (size_t)q_hidden * 22 * 4 : 0);
+  const size_t lds = (size_t)HD_ANCH * (boxLs + clsLs) * es;  // (the quality-head weights are scalar operands: no LDS copy)
   EY_CHECK(lds <= 160 * 1024, "head_decode: nc=%d needs %zu B of LDS", nc, lds);
   dim3 grid((unsigned)nblk);
   hipStream_t st = (hipStream_t)stream;
