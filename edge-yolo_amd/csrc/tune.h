@@ -35,6 +35,11 @@ struct EyTune {
   long tz_kmask = 168;          // Toeplitz dsconv kernel: bit k set = use it for kernel size k (168 = k 3, 5, 7)
   long tz_minpx = 100000;       // ... k = 3/5 only on maps with at least this many pixels (k = 7 always)
   long ds_strip = 1;            // dsconv register-strip kernel (0 = off)
+  long dsb_pair = 1;            // DSBottleneck pair (k3 -> k5/k7 DSConv + residual) as one band kernel on small maps (0 = two launches)
+  long dsb_max_px = 100000;     // ... for maps up to this many pixels (B x H x W)
+  long dsb_rb = 0;              // ... developer knob: rows per band (0 = cost rule)
+  long dsb_p2 = 0;              // ... developer knob: strip length of the second stage (1, 2, 4; 0 = rule)
+  long dsb_fixed = 100;         // ... cost rule: fixed cost of a workgroup in stencil row-taps
   long stem_mfma = 1;           // MFMA stem kernel (0 = VALU stem)
   long linattn_mfma = 1;        // MFMA linear-attention kernel (0 = fp32 VALU kernel)
   long softattn_mfma = 1;       // MFMA softmax-attention kernel (0 = fp32 VALU kernel)

@@ -315,15 +315,10 @@ def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     return out
 
 
-def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
-    """Fused depthwise->pointwise: y = res + act(pw1x1(dw_act(dw_kxk(x) + dw_bias)) + bias).  Returns None when the shape is
-    outside the fused kernel (caller then runs the two-kernel form)."""
-    L.require_device(x, "dsconv")
-    x = L.as_nhwc(x)
-    B, c, H, W = x.shape
-    es = x.element_size()
-    if c % 8 or c > 256 or (L.cstride(x) * es) % 16 or x.data_ptr() % 16:
-        return None
+def _dsconv_pack(mod, x, dw_fn, pw_fn, k):
+    """Device operands of one fused DSConv, cached on the module per (dtype, device): depthwise weights [k][k][C], depthwise bias,
+    packed pointwise weights (BN folded), bias, Cout, Toeplitz form of the depthwise weights (C 16 / 32) or None."""
+    c = x.shape[1]
 
     def build():
         wd, bd = dw_fn()
@@ -340,7 +335,52 @@ def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
         return (wk, (bd.to(x.device).float().contiguous() if bd is not None else None), pack_conv_weight(wp, x.dtype, x.device),
                 (bp.to(x.device).contiguous() if bp is not None else None), wp.shape[0], tz)
 
-    wk, dwb, wp, bias, cout, tz = mod._packed(_dev_key(x, "dsfused"), build)
+    return mod._packed(_dev_key(x, "dsfused"), build)
+
+
+def dsb_pair(cv1, cv2, x, add, out=None):
+    """DSBottleneck.forward (reference block.py:1496-1503) as one launch: y = [x +] cv2(cv1(x)) for two DSConv modules (k 3 -> 5 / 7, equal
+    widths of 32 / 64 channels, f16, small maps).  Bit-identical to the two ey_dsconv launches.  Returns None when the shape is outside
+    the fused kernel (nothing launched): the caller then runs the two DSConvs."""
+    L.require_device(x, "dsb_pair")
+    if RECORD is not None or x.dtype != torch.float16:
+        return None
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    k1, k2 = cv1.dw.kernel_size[0], cv2.dw.kernel_size[0]
+    if (c not in (32, 64) or k1 != 3 or k2 not in (5, 7) or cv1.pw.out_channels != c or cv2.pw.out_channels != c or cv2.dw.in_channels != c
+            or any(m.dw.stride != (1, 1) or m.dw.dilation != (1, 1) or m.dw.padding != (m.dw.kernel_size[0] // 2,) * 2 or m.dw.bias is not None for m in (cv1, cv2))
+            or (L.cstride(x) * 2) % 16 or x.data_ptr() % 16):
+        return None
+    if out is None:
+        out = L.empty_nhwc(B, c, H, W, x.dtype, x.device)
+    elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, c, H, W):
+        raise ValueError("dsb_pair: out= must be an NHWC view of the output shape")
+    if (L.cstride(out) * 2) % 16 or out.data_ptr() % 16:
+        return None
+    wk1, _, wp1, b1, _, _ = _dsconv_pack(cv1, x, cv1._dw_folded, cv1._pw_folded, k1)
+    wk2, _, wp2, b2, _, _ = _dsconv_pack(cv2, x, cv2._dw_folded, cv2._pw_folded, k2)
+    try:
+        with _tr(f"dsb_pair_kernel<{k1},{k2}>", _nb(x, out), 2.0 * B * H * W * c * (k1 * k1 + k2 * k2 + 2 * c), note=f"C{c} {H}x{W}{' +res' if add else ''}"):
+            L.check(L.lib().ey_dsb_pair(L.dtype_code(x.dtype), B, H, W, c, k1, k2, L.ACT_SILU, x.data_ptr(), L.cstride(x), wk1.data_ptr(), wp1.data_ptr(),
+                                        b1.data_ptr() if b1 is not None else None, wk2.data_ptr(), wp2.data_ptr(), b2.data_ptr() if b2 is not None else None,
+                                        1 if add else 0, out.data_ptr(), L.cstride(out), L.stream()), "ey_dsb_pair")
+    except NotImplementedError:  # EY_EUNSUPPORTED: returned before anything is launched
+        return None
+    return out
+
+
+def dsconv(mod, x, dw_fn, pw_fn, k, act, out=None, res=None, dw_act=0):
+    """Fused depthwise->pointwise: y = res + act(pw1x1(dw_act(dw_kxk(x) + dw_bias)) + bias).  Returns None when the shape is
+    outside the fused kernel (caller then runs the two-kernel form)."""
+    L.require_device(x, "dsconv")
+    x = L.as_nhwc(x)
+    B, c, H, W = x.shape
+    es = x.element_size()
+    if c % 8 or c > 256 or (L.cstride(x) * es) % 16 or x.data_ptr() % 16:
+        return None
+
+    wk, dwb, wp, bias, cout, tz = _dsconv_pack(mod, x, dw_fn, pw_fn, k)
     if out is None:
         out = L.empty_nhwc(B, cout, H, W, x.dtype, x.device)
     elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, cout, H, W):

@@ -41,6 +41,8 @@ class _Launch:
         self.s.record()  # torch's current stream == the stream the kernel is launched on (_lib.stream())
 
     def __exit__(self, *a):
+        if a and a[0] is not None:  # the call raised (e.g. EY_EUNSUPPORTED: nothing was launched): no record
+            return
         self.e.record()
         self.tr.records.append((self.kernel, self.b, self.f, self.s, self.e, self.note, self.kernels))
 

@@ -158,6 +158,16 @@ int ey_dsconv_tz(int dtype, int B, int H, int W, int Cin, int Cout, int k, int a
                  const void* w_dw_kkc, const void* w_dw_toeplitz, const float* dw_bias, int dw_act, const void* w_pw_packed, const float* bias,
                  void* y, int y_cstride, const void* res, int res_cstride, ey_stream_t stream);
 
+/* ---- K2 pair: DSBottleneck.forward (block.py:1496-1503) as one kernel on small maps (f16; C = c1 = c_ = c2 in {32, 64}; k1 = 3,
+ * k2 in {5, 7}; stride 1):   y = [x +] DSConv_k2( DSConv_k1(x) ),  DSConv_k(t) = act( pw1x1( dw_kxk(t) ) + bias ).
+ * A workgroup owns a band of rows of one image and recomputes the first DSConv on the second one's halo rows; the intermediate
+ * tensor stays in LDS, rounded to f16 exactly as the two-launch form (2 x ey_dsconv) stores it: the result is bit-identical to that
+ * form.  Weights as for ey_dsconv (no depthwise bias).  Returns EY_EUNSUPPORTED -- before anything is launched -- for every other
+ * shape; the caller then issues the two ey_dsconv calls. */
+int ey_dsb_pair(int dtype, int B, int H, int W, int C, int k1, int k2, int act, const void* x, int x_cstride, const void* w_dw1_kkc,
+                const void* w_pw1_packed, const float* bias1, const void* w_dw2_kkc, const void* w_pw2_packed, const float* bias2, int add_residual,
+                void* y, int y_cstride, ey_stream_t stream);
+
 /* Kernel the last ey_dsconv / ey_dsconv_tz on this thread launched (profiling labels): 1 = dsconv_kernel (LDS tile),
  * 2 = dsconv_strip_kernel (register strip), 3 = dsconv_tz_kernel (Toeplitz MFMA). */
 int ey_dsconv_last_variant(void);

@@ -39,7 +39,7 @@ n = len(t.records) // a.reps
 tot = 0.0
 print(f"{'#':>3} {'kernel':34s} {'shape':34s} {'us':>8s} {'GB/s':>8s} {'TF/s':>7s}")
 for i in range(n):
-    k, b, f, _, _, note = t.records[i]
+    k, b, f, _, _, note, _ = t.records[i]
     us = sum(t.records[i + r * n][3].elapsed_time(t.records[i + r * n][4]) for r in range(a.reps)) / a.reps * 1e3
     tot += us
     print(f"{i:3d} {k:34s} {note:34s} {us:8.1f} {b / us / 1e3:8.0f} {f / us / 1e6:7.1f}")
