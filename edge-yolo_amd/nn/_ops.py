@@ -290,6 +290,46 @@ def stem_conv(mod, x, folded_fn, act, out_dtype, out=None):
     return out
 
 
+def stem_pair(m0, m1, x, out=None):
+    """Layers 0 + 1 (Conv 3->16 k3 s2 + Conv 16->32 k3 s2, both BN + SiLU; reference conv.py:41-59) as one launch from the NCHW-contiguous f16
+    image: the stem's output -- the largest tensor of the forward, with one consumer -- stays in LDS.  Bit-identical to the two launches.
+    Returns None (nothing launched) when the modules / shape are outside the fused kernel."""
+    L.require_device(x, "stem_pair")
+    if RECORD is not None or x.dtype != torch.float16 or x.dim() != 4 or not x.is_contiguous() or L.is_nhwc_view(x):
+        return None
+    c0, c1 = m0.conv, m1.conv
+    B, cin, H, W = x.shape
+    if (cin != 3 or c0.in_channels != 3 or c0.out_channels != 16 or c1.in_channels != 16 or c1.out_channels != 32 or W % 8 or x.data_ptr() % 16
+            or any(c.kernel_size != (3, 3) or c.stride != (2, 2) or c.padding != (1, 1) or c.dilation != (1, 1) or c.groups != 1 for c in (c0, c1))):
+        return None
+
+    def build0():
+        w, b = m0.folded()
+        return w.to(x.device).contiguous(), b.to(x.device).contiguous()
+
+    def build1():
+        w, b = m1.folded()
+        pk = pack_conv_weight(w, x.dtype, x.device)  # (the tuple ops.conv2d caches under the same key)
+        return pk, b.to(x.device).float().contiguous(), w.shape[0], pk.numel() // x.element_size()
+
+    w0, b0 = m0._packed(("stem", x.device), build0)
+    w1, b1 = m1._packed(_dev_key(x, "igemm"), build1)[:2]
+    Hs, Ws = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Ho, Wo = (Hs - 1) // 2 + 1, (Ws - 1) // 2 + 1
+    if out is None:
+        out = L.empty_nhwc(B, 32, Ho, Wo, x.dtype, x.device)
+    elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, 32, Ho, Wo) or out.dtype != x.dtype:
+        raise ValueError("stem_pair: out= must be an NHWC view of the output shape")
+    from .modules.conv import _act_code
+    try:
+        with _tr("stem_pair_kernel", _nb(x, out), 2.0 * B * (Hs * Ws * 16 * 27 + Ho * Wo * 32 * 144), note=f"3->16->32 {H}x{W}"):
+            L.check(L.lib().ey_stem_pair(B, H, W, x.data_ptr(), w0.data_ptr(), b0.data_ptr(), _act_code(m0.act), 32, w1.data_ptr(), b1.data_ptr(), _act_code(m1.act),
+                                         out.data_ptr(), L.cstride(out), L.stream()), "ey_stem_pair")
+    except NotImplementedError:  # EY_EUNSUPPORTED: returned before anything is launched
+        return None
+    return out
+
+
 def dwconv(mod, x, folded_fn, k, act, out=None, tag=""):
     L.require_device(x, "dwconv")
     x = L.as_nhwc(x)

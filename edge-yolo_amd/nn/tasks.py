@@ -182,6 +182,13 @@ class BaseModel(nn.Module):
                     i = j
                     continue
             m = self.model[i]
+            if i == 0 and hi > 1 and 0 not in self.save and torch.is_tensor(x) and type(m) is Conv and type(self.model[1]) is Conv and self.model[1].f == -1:
+                got = ops.stem_pair(m, self.model[1], x)  # layers 0 + 1 as one kernel: the stem's output never leaves the chip
+                if got is not None:
+                    x = got
+                    y.extend([None, x if 1 in self.save else None])
+                    i = 2
+                    continue
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j2 == -1 else y[j2] for j2 in m.f]
             x = m(x, nms=head_nms) if (head_nms is not None and isinstance(m, Detect)) else m(x)

@@ -133,6 +133,13 @@ int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream);
 int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cout, int act, const void* x_nchw,
                  const float* w_oihw, const float* bias, void* y, int y_cstride, ey_stream_t stream);
 
+/* ---- layers 0 + 1 as one kernel (f16): y = act1( Conv3x3s2_{16->C1}( act0( Conv3x3s2_{3->16}(x) + bias0 ) ) + bias1 ), conv.py:41-59 twice.
+ * x: [B,3,H,W] contiguous f16 (W % 8 == 0); w0: fp32 [16][3][3][3] device; w1: ey_conv_pack_weight(EY_F16, C1, 16, 3, ...); C1 = 32.
+ * The (B,16,H/2,W/2) intermediate stays in LDS (rounded to f16 as ey_stem_conv stores it): bit-identical to ey_stem_conv + ey_conv2d.
+ * EY_EUNSUPPORTED (before anything is launched) for every other shape. */
+int ey_stem_pair(int B, int H, int W, const void* x_nchw, const float* w0_oihw, const float* bias0, int act0, int C1, const void* w1_packed,
+                 const float* bias1, int act1, void* y, int y_cstride, ey_stream_t stream);
+
 /* ---- K2/K3: depthwise kxk, stride 1, pad k/2 (+ optional bias + activation).  DSConv.dw (conv.py:94-97,102) and
  * DWConv (conv.py:124-129) in Detect.cv3 (head.py:68-69).  w: [k][k][C] in `dtype`; k in {3,5,7}; C%8==0. */
 int ey_dwconv(int dtype, int B, int H, int W, int C, int k, int act, const void* x, int x_cstride, const void* w_kkc,
