@@ -81,6 +81,7 @@ SIGNATURES = {
     "ey_dsconv_pack_toeplitz": (_i, [_i, _i, _vp, _vp, _sz]),
     "ey_dsconv_tz": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dsconv_last_variant": (_i, []),
+    "ey_conv_pw_conv3s2": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_stem_pair": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dsb_pair": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ey_dwt_haar": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),

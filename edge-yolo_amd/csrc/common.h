@@ -100,6 +100,15 @@ __device__ __forceinline__ void ey_fma8_mix(const Vec8<float>& a, const Vec8<flo
 // 1/(1+e^-x) with the hardware reciprocal (1 ulp) instead of the IEEE division sequence (10+ instructions)
 __device__ __forceinline__ float ey_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
+// x * sigmoid(x) as an fp32 value of its own.  Left to itself the compiler may fold the multiply into the conversion to f16 that
+// follows (v_fma_mixlo_f16: ONE rounding) in one kernel and not in another (v_mul_f32 + v_cvt_f16_f32: two roundings).  The conv
+// kernels round twice; the fused multi-layer kernels that promise the bits of their multi-launch form pin that here.
+__device__ __forceinline__ float ey_silu_rn(float x) {
+  float p = x * ey_sigmoid(x);
+  asm("" : "+v"(p));
+  return p;
+}
+
 // ---- buffer loads with hardware range checking: an out-of-range byte offset returns zeros, so padding taps,
 // M tails and channel tails need no branches (offset EY_OOB is beyond any view: views are < 2 GiB, checked on the host)
 #define EY_OOB 0x80000000u

@@ -14,16 +14,7 @@
 #include "tune.h"
 
 typedef f16 f16x4v __attribute__((ext_vector_type(4)));
-// x * sigmoid(x) as an fp32 value of its own: left to itself the compiler may fold the multiply into the conversion to f16 that follows
-// (v_fma_mixlo_f16: ONE rounding) in one kernel and not in another (v_mul_f32 + v_cvt_f16_f32: two roundings) -- the two-launch kernels
-// round twice, and this kernel promises their bits.
-__device__ __forceinline__ float ey_silu_rn(float x) {
-  float p = x * ey_sigmoid(x);
-  asm("" : "+v"(p));
-  return p;
-}
 #define ST2_SP 20  // pitch (halves) of a stem pixel's 16 channels in LDS: 40 B
-
 template <int TH, int TW, int NT1>
 __global__ __launch_bounds__(256) void stem_pair_kernel(int B, int H, int W, int Hs, int Ws, int Ho, int Wo, const f16* __restrict__ x, unsigned xbytes,
                                                         const float* __restrict__ w0, const float* __restrict__ bias0, const f16* __restrict__ w1, int Kpad1,

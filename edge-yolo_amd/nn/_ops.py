@@ -290,6 +290,56 @@ def stem_conv(mod, x, folded_fn, act, out_dtype, out=None):
     return out
 
 
+def _conv_pack(mod, x0, cin, k, tag=""):
+    """Packed MFMA weights + fp32 bias of a plain Conv module, under the cache key (and with the tuple layout) ops.conv2d uses."""
+    def build():
+        w, b = mod.folded()
+        if w.shape[1] != cin or w.shape[2] != k:
+            raise ValueError(f"conv weight {tuple(w.shape)} does not match Cin={cin} k={k}")
+        pk = pack_conv_weight(w, x0.dtype, x0.device)
+        return pk, (None if b is None else b.to(x0.device).float().contiguous()), w.shape[0], pk.numel() // x0.element_size()
+
+    return mod._packed(_dev_key(x0, "igemm" + tag), build)
+
+
+def pw_conv3s2(cv2, conv3, srcs, out=None):
+    """A block's closing 1x1 Conv over a two-part virtual concat + the stride-2 3x3 Conv that follows it (layers 2 -> 3 of the n-scale
+    backbones: DSC3K2_Wavelet.cv2 / C3k2.cv2, reference block.py:357-396,3783-3788, then conv.py:41-59) as one launch; the 64-channel map
+    between them stays in LDS.  Bit-identical to the two launches.  Returns None (nothing launched) outside the fused kernel's shapes."""
+    if RECORD is not None or len(srcs) != 2 or any(isinstance(t, VirtualCat) for t in srcs):
+        return None
+    x0 = srcs[0]
+    L.require_device(x0, "pw_conv3s2")
+    if x0.dtype != torch.float16:
+        return None
+    srcs = [L.as_nhwc(t) for t in srcs]
+    B, _, H, W = srcs[0].shape
+    c1, c3 = cv2.conv, conv3.conv
+    from .modules.conv import _act_code
+    if (tuple(srcs[1].shape[0:1] + srcs[1].shape[2:]) != (B, H, W) or c1.kernel_size != (1, 1) or c1.stride != (1, 1) or c1.groups != 1 or c1.out_channels != 64
+            or c3.kernel_size != (3, 3) or c3.stride != (2, 2) or c3.padding != (1, 1) or c3.dilation != (1, 1) or c3.groups != 1 or c3.in_channels != 64
+            or c3.out_channels != 64 or c1.in_channels != srcs[0].shape[1] + srcs[1].shape[1] or any(t.shape[1] > 32 or t.shape[1] % 8 for t in srcs)
+            or _act_code(cv2.act) != L.ACT_SILU or _act_code(conv3.act) != L.ACT_SILU
+            or any((L.cstride(t) * 2) % 16 or t.data_ptr() % 16 for t in srcs)):
+        return None
+    w1, b1 = _conv_pack(cv2, x0, c1.in_channels, 1)[:2]
+    w2, b2 = _conv_pack(conv3, x0, 64, 3)[:2]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = L.empty_nhwc(B, 64, Ho, Wo, x0.dtype, x0.device)
+    elif not L.is_nhwc_view(out) or tuple(out.shape) != (B, 64, Ho, Wo) or out.dtype != x0.dtype:
+        raise ValueError("pw_conv3s2: out= must be an NHWC view of the output shape")
+    c0n, c1n = srcs[0].shape[1], srcs[1].shape[1]
+    try:
+        with _tr("pw3_kernel", _nb(srcs[0], srcs[1], out), 2.0 * B * (H * W * 64 * (c0n + c1n) + Ho * Wo * 64 * 576), note=f"{c0n}+{c1n}->64 k1 -> 64 k3s2 {H}x{W}"):
+            L.check(L.lib().ey_conv_pw_conv3s2(L.dtype_code(x0.dtype), B, H, W, srcs[0].data_ptr(), c0n, L.cstride(srcs[0]), srcs[1].data_ptr(), c1n, L.cstride(srcs[1]), 64,
+                                               w1.data_ptr(), b1.data_ptr(), L.ACT_SILU, 64, w2.data_ptr(), b2.data_ptr(), L.ACT_SILU, out.data_ptr(), L.cstride(out),
+                                               L.stream()), "ey_conv_pw_conv3s2")
+    except NotImplementedError:  # EY_EUNSUPPORTED: returned before anything is launched
+        return None
+    return out
+
+
 def stem_pair(m0, m1, x, out=None):
     """Layers 0 + 1 (Conv 3->16 k3 s2 + Conv 16->32 k3 s2, both BN + SiLU; reference conv.py:41-59) as one launch from the NCHW-contiguous f16
     image: the stem's output -- the largest tensor of the forward, with one consumer -- stays in LDS.  Bit-identical to the two launches.
@@ -307,13 +357,8 @@ def stem_pair(m0, m1, x, out=None):
         w, b = m0.folded()
         return w.to(x.device).contiguous(), b.to(x.device).contiguous()
 
-    def build1():
-        w, b = m1.folded()
-        pk = pack_conv_weight(w, x.dtype, x.device)  # (the tuple ops.conv2d caches under the same key)
-        return pk, b.to(x.device).float().contiguous(), w.shape[0], pk.numel() // x.element_size()
-
     w0, b0 = m0._packed(("stem", x.device), build0)
-    w1, b1 = m1._packed(_dev_key(x, "igemm"), build1)[:2]
+    w1, b1 = _conv_pack(m1, x, 16, 3)[:2]
     Hs, Ws = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Ho, Wo = (Hs - 1) // 2 + 1, (Ws - 1) // 2 + 1
     if out is None:

@@ -89,7 +89,9 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, tail=None):
+        """tail (extension): the stride-2 3x3 Conv module that consumes this block's output and nothing else does -- cv2 and that conv then
+        run as one kernel where the shape allows (ops.pw_conv3s2), and the TAIL's output is returned."""
         B, _, H, W = x.shape  # x may be a VirtualCat (upsample+concat folded into cv1)
         c, n = self.c, len(self.m)
         buf = L.empty_nhwc(B, (2 + n) * c, H, W, x.dtype, x.device)
@@ -448,7 +450,9 @@ class DSC3K2_Wavelet(nn.Module):
             self.m = nn.ModuleList(DSBottleneck(self.c, self.c, shortcut=shortcut, e=1.0, k1=k1, k2=k2, d2=d2) for _ in range(n))
         self.wave = _WaveletEnhancer(self.c, use_ds=use_ds, wave=wave, mode=mode)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, tail=None):
+        """tail (extension): the stride-2 3x3 Conv module that consumes this block's output and nothing else does -- cv2 and that conv then
+        run as one kernel where the shape allows (ops.pw_conv3s2), and the TAIL's output is returned."""
         B, _, H, W = x.shape  # x may be a VirtualCat (upsample+concat folded into cv1)
         c, n = self.c, len(self.m)
         t = self.cv1(x)  # [a | b]
@@ -457,4 +461,7 @@ class DSC3K2_Wavelet(nn.Module):
         for i, m in enumerate(self.m):
             m(_slot(buf, i, c), out=_slot(buf, 1 + i, c))
         # cat(a, wave(b), m...) is never built: cv2 reads the two buffers as one virtual concat
+        if tail is not None:
+            y = ops.pw_conv3s2(self.cv2, tail, [t[:, :c], buf])
+            return y if y is not None else tail(ops.conv2d(self.cv2, [t[:, :c], buf], self.cv2.folded, 1, 1, 0, L.ACT_SILU))
         return ops.conv2d(self.cv2, [t[:, :c], buf], self.cv2.folded, 1, 1, 0, L.ACT_SILU, out=out)

@@ -191,6 +191,12 @@ class BaseModel(nn.Module):
                     continue
             if m.f != -1:
                 x = y[m.f] if isinstance(m.f, int) else [x if j2 == -1 else y[j2] for j2 in m.f]
+            if (type(m) is DSC3K2_Wavelet and i + 1 < hi and i not in self.save and type(self.model[i + 1]) is Conv and self.model[i + 1].f == -1
+                    and self.model[i + 1].conv.stride == (2, 2) and self.model[i + 1].conv.kernel_size == (3, 3)):
+                x = m(x, tail=self.model[i + 1])  # the block's closing 1x1 + the down-sampling conv behind it as one kernel where the shape allows
+                y.extend([None, x if i + 1 in self.save else None])
+                i += 2
+                continue
             x = m(x, nms=head_nms) if (head_nms is not None and isinstance(m, Detect)) else m(x)
             y.append(x if m.i in self.save else None)
             i += 1

@@ -133,6 +133,15 @@ int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream);
 int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cout, int act, const void* x_nchw,
                  const float* w_oihw, const float* bias, void* y, int y_cstride, ey_stream_t stream);
 
+/* ---- a block's closing 1x1 conv over a two-part virtual concat + the stride-2 3x3 conv behind it, as one kernel (f16; Cmid = Cout = 64;
+ * C0, C1 <= 32, multiples of 8; both bias + SiLU):   y = act2( Conv3x3s2( act1( Conv1x1( cat(src0, src1) ) + bias1 ) ) + bias2 )
+ * = DSC3K2_Wavelet.cv2 / C2f.cv2 (block.py:357-396,3783-3788) + the next backbone layer Conv(64,64,3,2) (conv.py:41-59).  The (B,64,H,W)
+ * map between them stays in LDS, rounded to f16 as ey_conv2d stores it: bit-identical to the two ey_conv2d calls.  w1: ey_conv_pack_weight
+ * (EY_F16, 64, C0 + C1, 1), w2: (EY_F16, 64, 64, 3).  EY_EUNSUPPORTED (before anything is launched) for every other shape. */
+int ey_conv_pw_conv3s2(int dtype, int B, int H, int W, const void* src0, int C0, int cstride0, const void* src1, int C1, int cstride1, int Cmid,
+                       const void* w1_packed, const float* bias1, int act1, int Cout, const void* w2_packed, const float* bias2, int act2, void* y,
+                       int y_cstride, ey_stream_t stream);
+
 /* ---- layers 0 + 1 as one kernel (f16): y = act1( Conv3x3s2_{16->C1}( act0( Conv3x3s2_{3->16}(x) + bias0 ) ) + bias1 ), conv.py:41-59 twice.
  * x: [B,3,H,W] contiguous f16 (W % 8 == 0); w0: fp32 [16][3][3][3] device; w1: ey_conv_pack_weight(EY_F16, C1, 16, 3, ...); C1 = 32.
  * The (B,16,H/2,W/2) intermediate stays in LDS (rounded to f16 as ey_stem_conv stores it): bit-identical to ey_stem_conv + ey_conv2d.

@@ -1,0 +1,66 @@
+"""-m gpu: a block's closing 1x1 conv + the stride-2 3x3 conv behind it as one kernel (ey_conv_pw_conv3s2; reference block.py:3783-3788 +
+conv.py:41-59): bit-identical to the two launches at the benchmarked shape and at ragged ones, within the f16 tolerance of the CPU oracle,
+and taken by the model for layers 2 -> 3."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as om
+import synthdata as synth  # noqa: E402
+from gpu_util import check, load_synth, to_dev  # noqa: E402
+from test_gpu_dsb import _traced, tuned  # noqa: E402
+
+
+def _mods(cin):
+    from edge_yolo_amd.nn import modules as M
+    cv2, c3 = M.Conv(cin, 64, 1, 1), M.Conv(64, 64, 3, 2)
+    sd = {**load_synth(cv2, "p1"), **load_synth(c3, "p3")}
+    return to_dev(cv2, torch.float16), to_dev(c3, torch.float16), sd
+
+
+@pytest.mark.parametrize("b,h,w,c0,c1", [(32, 160, 160, 16, 32), (2, 33, 47, 16, 32), (3, 16, 16, 32, 32), (1, 9, 70, 8, 24), (2, 1, 1, 16, 16), (1, 130, 18, 32, 8)])
+def test_pw3_bitwise_and_oracle(b, h, w, c0, c1):
+    from edge_yolo_amd import _lib as L
+    from edge_yolo_amd.nn import _ops
+    cv2, c3, sd = _mods(c0 + c1)
+    x = synth.synth_images(b, h, w, seed=h + w, c=c0 + c1) - 0.5
+    # the two sources as the block provides them: channel slices of wider NHWC buffers
+    buf0 = L.empty_nhwc(b, 2 * c0, h, w, torch.float16, "cuda")
+    buf0.copy_(torch.cat([x[:, :c0], x[:, :c0]], 1).half())
+    buf1 = L.empty_nhwc(b, c1, h, w, torch.float16, "cuda")
+    buf1.copy_(x[:, c0:].half())
+    srcs = [buf0[:, :c0], buf1]
+    with tuned(pw3_min_px=0):
+        got, ker = _traced(lambda: _ops.pw_conv3s2(cv2, c3, srcs))
+    assert ker == ["pw3_kernel"], ker
+    two, ker2 = _traced(lambda: c3(_ops.conv2d(cv2, srcs, cv2.folded, 1, 1, 0, L.ACT_SILU)))
+    assert len(ker2) == 2
+    assert torch.equal(got, two), f"max |diff| {float((got.float() - two.float()).abs().max())}"
+    if b * h * w <= 100_000:
+        xr = x.half().float()
+        check(got, om.conv(sd, "p3", om.conv(sd, "p1", xr, 1, 1), 3, 2), torch.float16, what=f"pw3 {h}x{w}")
+
+
+def test_model_takes_the_fused_layers_2_3():
+    import bench
+    model, _ = bench.build_model("yolo11n-test.yaml", torch.float16, torch.device("cuda:0"))
+    x = synth.synth_images(2, 128, 160).to("cuda", torch.float16)
+    with tuned(pw3_min_px=0):
+        (pred, _), ker = _traced(lambda: model(x))
+    assert ker.count("pw3_kernel") == 1, ker
+    with tuned(pw3=0):
+        (pred2, _), ker2 = _traced(lambda: model(x))
+    assert "pw3_kernel" not in ker2 and len(ker2) == len(ker) + 1
+    assert torch.equal(pred, pred2)
+
+
+def test_small_maps_and_other_widths_fall_back():
+    from edge_yolo_amd import _lib as L
+    from edge_yolo_amd.nn import _ops, modules as M
+    cv2, c3, _ = _mods(48)
+    a, bb = L.empty_nhwc(1, 16, 8, 8, torch.float16, "cuda"), L.empty_nhwc(1, 32, 8, 8, torch.float16, "cuda")
+    assert _ops.pw_conv3s2(cv2, c3, [a, bb]) is None  # below pw3_min_px
+    wide = to_dev(M.Conv(64, 128, 3, 2), torch.float16)
+    with tuned(pw3_min_px=0):
+        assert _ops.pw_conv3s2(cv2, wide, [a, bb]) is None
