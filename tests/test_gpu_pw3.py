@@ -19,8 +19,9 @@ def _mods(cin):
     return to_dev(cv2, torch.float16), to_dev(c3, torch.float16), sd
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("b,h,w,c0,c1", [(32, 160, 160, 16, 32), (2, 33, 47, 16, 32), (3, 16, 16, 32, 32), (1, 9, 70, 8, 24), (2, 1, 1, 16, 16), (1, 130, 18, 32, 8)])
-def test_pw3_bitwise_and_oracle(b, h, w, c0, c1):
+def test_pw3_bitwise_and_oracle(b, h, w, c0, c1, form):
     from edge_yolo_amd import _lib as L
     from edge_yolo_amd.nn import _ops
     cv2, c3, sd = _mods(c0 + c1)
@@ -31,7 +32,7 @@ def test_pw3_bitwise_and_oracle(b, h, w, c0, c1):
     buf1 = L.empty_nhwc(b, c1, h, w, torch.float16, "cuda")
     buf1.copy_(x[:, c0:].half())
     srcs = [buf0[:, :c0], buf1]
-    with tuned(pw3_min_px=0):
+    with tuned(pw3_min_px=0, pw3=form):  # 1: two 256-thread workgroups per CU, weights in registers; 2: one of 512, weights in LDS
         got, ker = _traced(lambda: _ops.pw_conv3s2(cv2, c3, srcs))
     assert ker == ["pw3_kernel"], ker
     two, ker2 = _traced(lambda: c3(_ops.conv2d(cv2, srcs, cv2.folded, 1, 1, 0, L.ACT_SILU)))
