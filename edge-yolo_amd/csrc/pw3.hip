@@ -22,7 +22,7 @@ struct Pw3P {
   const void* w1; int Kpad1; const float* b1;
   const void* w2; int Kpad2; const float* b2;
   void* y; int yCs;
-  int tilesX, tilesY, ntile;
+  int tilesX, tilesY, ntile, skew;
 };
 
 #define PW3_TH 8
@@ -203,6 +203,10 @@ __global__ __launch_bounds__(256, 2) void pw3b_kernel(Pw3P p) {
   const bool cok0 = 8 * g < p.C0, cok1 = 8 * g < p.C1;
   const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(p.src0, p.bytes0), rs1 = ey_rsrc(p.src1, p.bytes1);
   const int tiles_img = p.tilesX * p.tilesY;
+  // the two workgroups of a CU start together and every tile costs the same: left alone they run phase 1 (VALU) at the same time and
+  // phase 2 (MFMA + LDS) at the same time.  The second half of the grid starts a fraction of a tile late.
+  if (blockIdx.x >= gridDim.x / 2)
+    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(16);
   for (int tile = blockIdx.x; tile < p.ntile; tile += gridDim.x) {
     const int b = tile / tiles_img, trem = tile - b * tiles_img;
     const int oy0 = (trem / p.tilesX) * PW3_TH, ox0 = (trem % p.tilesX) * PW3_TW;
@@ -310,6 +314,7 @@ extern "C" int ey_conv_pw_conv3s2(int dtype, int B, int H, int W, const void* sr
   const long ntile = (long)B * p.tilesX * p.tilesY;
   if (ntile >= (1L << 30)) return ey_set_error(EY_EUNSUPPORTED, "conv_pw_conv3s2: too many tiles");
   p.ntile = (int)ntile;
+  p.skew = (int)tune().pw3_skew;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;

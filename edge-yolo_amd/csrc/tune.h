@@ -42,6 +42,7 @@ struct EyTune {
   long dsb_fixed = 100;         // ... cost rule: fixed cost of a workgroup in stencil row-taps
   long stem_pair = 1;           // layers 0 + 1 (3 -> 16 -> 32, both 3x3 stride 2) as one kernel (0 = two launches; developer knob: 2 / 3 / 4 / 5 = 8x16 / 4x16 / 4x32 / 8x32 tiles)
   long pw3 = 1;                 // closing 1x1 of a block + the 64 -> 64 stride-2 3x3 behind it as one kernel (0 = two launches)
+  long pw3_skew = 8;            // ... start delay of the second half of the grid in units of 1024 clocks (anti-phase the two workgroups of a CU)
   long pw3_min_px = 100000;     // ... on maps with at least this many pixels (B x H x W)
   long stem_mfma = 1;           // MFMA stem kernel (0 = VALU stem)
   long linattn_mfma = 1;        // MFMA linear-attention kernel (0 = fp32 VALU kernel)

@@ -33,7 +33,8 @@ def timed(fn, reps=10):
 
 
 print(f"two launches: {timed(lambda: c3(_ops.conv2d(cv2, srcs, cv2.folded, 1, 1, 0, L.ACT_SILU), out=y)):6.1f} us")
-for form in (1, 2):
+for form, skew in ((2, 0), (1, 0), (1, 2), (1, 4), (1, 6), (1, 8), (1, 12)):
     L.check(L.lib().ey_tune_set(b"pw3", form), "t")
+    L.check(L.lib().ey_tune_set(b"pw3_skew", skew), "t")
     us = timed(lambda: _ops.pw_conv3s2(cv2, c3, srcs, out=y))
-    print(f"pw3 form {form}:   {us:6.1f} us  ({(B * 160 * 160 * 48 + y.numel()) * 2 / us / 1e3:5.0f} GB/s algorithmic)")
+    print(f"pw3 form {form} skew {skew}:   {us:6.1f} us  ({(B * 160 * 160 * 48 + y.numel()) * 2 / us / 1e3:5.0f} GB/s algorithmic)")
