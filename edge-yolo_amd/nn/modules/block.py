@@ -73,9 +73,6 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x, out=None):
-        y = ops.dsb_pair(self.cv1, self.cv2, x, self.add, out=out)  # both DSConvs + the residual as one band kernel on the small maps
-        if y is not None:
-            return y
         return self.cv2(self.cv1(x), out=out, res=x if self.add else None)
 
 
