@@ -443,6 +443,13 @@ def dsb_pair(cv1, cv2, x, add, out=None):
         raise ValueError("dsb_pair: out= must be an NHWC view of the output shape")
     if (L.cstride(out) * 2) % 16 or out.data_ptr() % 16:
         return None
+    base = x.untyped_storage().data_ptr()
+    if out.untyped_storage().data_ptr() == base:
+        # same buffer (channel slots of one concat buffer): fine while the channel ranges are disjoint; an overlap (in-place update) would race --
+        # a workgroup reads halo rows of x that lie in other workgroups' bands
+        cs = L.cstride(x)
+        if L.cstride(out) != cs or abs(((x.data_ptr() - base) // 2) % cs - ((out.data_ptr() - base) // 2) % cs) < c:
+            return None
     wk1, _, wp1, b1, _, _ = _dsconv_pack(cv1, x, cv1._dw_folded, cv1._pw_folded, k1)
     wk2, _, wp2, b2, _, _ = _dsconv_pack(cv2, x, cv2._dw_folded, cv2._pw_folded, k2)
     try:

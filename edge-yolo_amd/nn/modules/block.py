@@ -121,9 +121,21 @@ class C3(_Packed):
         # buf = [cv1(x) -> m(.) in place | cv2(x)]: the bottleneck chain rewrites slot 0 in place (its last conv reads a
         # temporary and adds slot 0 pixel-by-pixel as the residual), so cat() never happens
         buf = ops.conv2d(self, [x], self._cv12, 1, 1, 0, L.ACT_SILU, tag="cv12")
-        t = buf[:, :c_]
+        slot, t, spare = buf[:, :c_], buf[:, :c_], None
         for m in self.m:
-            t = m(t, out=buf[:, :c_])
+            if isinstance(m, DSBottleneck):
+                # a DSBottleneck may run as ONE band kernel whose workgroups read halo rows of their neighbours' input: never in place.
+                # The chain alternates between slot 0 and a spare buffer (n = 2: slot 0 -> spare -> slot 0)
+                if t.data_ptr() == slot.data_ptr():
+                    if spare is None:
+                        spare = L.empty_nhwc(B, c_, H, W, x.dtype, x.device)
+                    t = m(t, out=spare)
+                else:
+                    t = m(t, out=slot)
+            else:
+                t = m(t, out=slot)
+        if t.data_ptr() != slot.data_ptr():  # odd DSBottleneck count: the chain ended in the spare buffer -> cv3 reads [spare | cv2(x)] as a virtual concat
+            return ops.conv2d(self.cv3, [t, buf[:, c_:]], self.cv3.folded, 1, 1, 0, L.ACT_SILU, out=out)
         return self.cv3(buf, out=out)
 
 

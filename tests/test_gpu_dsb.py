@@ -106,3 +106,32 @@ def test_shapes_outside_the_kernel_run_as_two_launches():
     load_synth(m, "dsbf")
     y, ker = _traced(lambda: to_dev(m, torch.float32)((torch.rand(2, 32, 12, 12) - 0.5).cuda()))
     assert len(ker) == 2
+
+
+def test_in_place_update_never_takes_the_band_kernel():
+    """out aliasing x (the in-place bottleneck chain of C3) would let a workgroup read halo rows another one has already overwritten:
+    the wrapper refuses (two launches, which are element-wise safe), and DSC3k alternates between two buffers instead."""
+    from edge_yolo_amd import _lib as L
+    from edge_yolo_amd.nn import modules as M
+    m, _ = _module(32, 5, seed=3)
+    buf = L.empty_nhwc(3, 64, 20, 20, torch.float16, "cuda")
+    buf.copy_((torch.rand(3, 64, 20, 20) - 0.5).half())
+    want = m(buf[:, :32].clone())
+    got, ker = _traced(lambda: m(buf[:, :32], out=buf[:, :32]))
+    assert len(ker) == 2 and not any("dsb_pair" in k for k in ker), ker
+    assert torch.equal(got, want)
+    # neighbouring channel slots of one buffer (DSC3K2_Wavelet's chain) are disjoint: the band kernel runs
+    got2, ker2 = _traced(lambda: m(buf[:, 32:], out=buf[:, :32]))
+    assert ker2 == ["dsb_pair_kernel<3,5>"]
+    # DSC3k (n = 2): both pairs as band kernels, same bits as the two-launch form, oracle within the f16 tolerance
+    blk = M.DSC3k(64, 64, n=2, k1=3, k2=5)
+    sd = load_synth(blk, "dsc3k")
+    blk = to_dev(blk, torch.float16)
+    x = synth.synth_images(8, 20, 20, seed=5, c=64) - 0.5
+    xd = x.to("cuda", torch.float16)
+    y, ker3 = _traced(lambda: blk(xd))
+    assert ker3.count("dsb_pair_kernel<3,5>") == 2, ker3
+    with tuned(dsb_pair=0):
+        y0 = blk(xd)
+    assert torch.equal(y, y0)
+    check(y, om.dsc3k(sd, "dsc3k", x.half().float(), 2, 3, 5), torch.float16, what="DSC3k")
