@@ -1360,6 +1360,115 @@ __global__ __launch_bounds__(256) void conv3r_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// N-split pointwise kernel for SMALL maps with MANY channels (1x1, stride 1, <= 2 sources, K = 128 ... 512, Cout a multiple of 128; f16):
+// the 20x20 / 40x40 layers of the neck and C2PSA (12.8 k / 51.2 k pixels at batch 32) are a few hundred 16-pixel tiles against a
+// 64-256 KB weight matrix.  The weight-stationary kernel stages a [128][K] tile per workgroup for a handful of tiles of work (staging
+// = most of its 17-19 us); the lean kernel would have every wave re-read its weight rows per 16 pixels.  Here the roles are swapped:
+// a 512-thread workgroup owns 64 pixels and a slab of 128 * NTW output channels; wave w owns 16 * NTW of those channels and keeps
+// ITS rows of the weight matrix -- KS * NTW fragments, read once from L2, no other wave needs them -- in registers; the 64 pixels
+// (all K channels, both sources, nearest-x2 sources resolved on the way) go to LDS once and every wave reads its B fragments there.
+// One barrier, 4 * KS * NTW MFMAs per wave, k-steps in the order of conv_ws_kernel (bit-identical results).
+template <int KS, int NTW>
+__global__ __launch_bounds__(512) void conv_pwn_kernel(ConvP p) {
+  typedef f16 T;
+  constexpr int MB = 4, PX = 16 * MB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* s_px = reinterpret_cast<T*>(smem);  // [PX][KP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
+  const int KP = p.LSw, KV = KS * 4;  // LDS pixel pitch (elements); 16-byte vectors per pixel
+  const int M = p.B * p.Ho * p.Wo, m0 = blockIdx.x * PX;
+  // this wave's channels: block of 128 (NTpack = 8) and n-blocks inside it
+  const int blk = NTW == 2 ? 2 * blockIdx.y + (wave >> 2) : blockIdx.y;
+  const int nt0 = NTW == 2 ? 2 * (wave & 3) : wave;
+  Vec8<T> af[KS][NTW];
+  {
+    const T* wr = (const T*)p.w + (long)(blk * 128 + nt0 * 16 + r) * p.Kpad + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) af[ks][nt].load(wr + (long)nt * 16 * p.Kpad + ks * 32);
+  }
+  {  // ---- pixels -> LDS (all requests of a thread first)
+    const __amdgpu_buffer_rsrc_t rs0 = ey_rsrc(p.src[0], p.srcBytes[0]);
+    const __amdgpu_buffer_rsrc_t rs1 = p.nsrc == 2 ? ey_rsrc(p.src[1], p.srcBytes[1]) : rs0;
+    const int C0 = p.srcC[0], hw = p.Ho * p.Wo;
+    const bool geo = p.srcUp[0] || (p.nsrc == 2 && p.srcUp[1]);
+    constexpr int NV = PX * KS * 4, U = (NV + 511) / 512;
+    Vec8<T> t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int v = tid + u * 512, px = v / KV, c = (v - px * KV) * 8, m = m0 + px;
+      const bool second = c >= C0;
+      const int s = second ? 1 : 0, cc = second ? c - C0 : c;
+      unsigned off = EY_OOB;
+      if (v < NV && m < M) {
+        if (geo) {
+          const int b = m / hw, rem = m - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo, up = p.srcUp[s];
+          off = (unsigned)(((((b * (p.H >> up)) + (oy >> up)) * (p.W >> up) + (ox >> up)) * p.srcCs[s] + cc) * 2);
+        } else {
+          off = (unsigned)((m * p.srcCs[s] + cc) * 2);
+        }
+      }
+      BufLoad8<T>::load(t[u], second ? rs1 : rs0, off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int v = tid + u * 512, px = v / KV, c = (v - px * KV) * 8;
+      if (v < NV) t[u].store(s_px + px * KP + c);
+    }
+  }
+  __syncthreads();
+  f32x4 acc[MB][NTW];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[mb][nt] = (f32x4)0.f;
+  const T* bp = s_px + r * KP + 8 * g;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    Vec8<T> bq[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) bq[mb].load(bp + mb * 16 * KP + ks * 32);
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) acc[mb][nt] = mma16(af[ks][nt], bq[mb], acc[mb][nt]);
+  }
+  // ---- epilogue: lane (r, g) holds channels ch0 .. ch0 + 4 NTW of pixel m0 + 16 mb + r (NTpack = 8 row permutation)
+  const int ch0 = blk * 128 + 32 * g + 4 * nt0;
+  float bias[4 * NTW];
+#pragma unroll
+  for (int i = 0; i < 4 * NTW; ++i) bias[i] = p.bias ? p.bias[ch0 + i] : 0.f;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m = m0 + mb * 16 + r;
+    if (m >= M) continue;
+    float v[4 * NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[4 * nt + j] = acc[mb][nt][j] + bias[4 * nt + j];
+    if (p.act == EY_ACT_SILU) {
+#pragma unroll
+      for (int i = 0; i < 4 * NTW; ++i) v[i] = v[i] * ey_sigmoid(v[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4 * NTW; ++i) v[i] = ey_act(v[i], p.act) * p.out_scale;
+    }
+    T* yp = (T*)p.y + (long)m * p.yCs + ch0;
+    if constexpr (NTW == 2) {
+      Vec8<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.set(j, v[j]);
+      o.store(yp);
+    } else {
+      const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+      *reinterpret_cast<f16x4*>(yp) = o;
+    }
+  }
+}
+
+// ================================================================================================================
 // Lean pointwise kernel (1x1, stride 1, <= 2 sources) for maps up to ~80x80.  Measured on MI355X (tools/micro): a lone
 // wave retires about one instruction per 2.5 ns and a kernel launch costs 1.6 us, so for layers that move a few MB the
 // run time is the per-wave instruction count plus the memory round trips, not bandwidth.  Hence: no LDS, no barrier,
@@ -2344,6 +2453,56 @@ static int dispatch_pw(ConvP p, int ngroup, hipStream_t st) {
   return 0;
 }
 
+// ---- N-split pointwise kernel (conv_pwn_kernel): small maps, K = 128 ... 512, Cout % 128 == 0
+template <int KS, int NTW>
+static int pwn_launch(ConvP p, hipStream_t st) {
+  int units = KS * 4;
+  while ((units & 3) != 2) ++units;  // LDS pixel pitch: 2 (mod 4) 16-byte units (conflict-free fragment reads)
+  p.LSw = units * 8;
+  const size_t lds = (size_t)64 * p.LSw * 2;
+  static bool reserved = false;
+  if (lds > 64 * 1024 && !reserved) {
+    if (hipFuncSetAttribute((const void*)conv_pwn_kernel<KS, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ey_set_error(EY_ELAUNCH, "conv(pwn): cannot reserve %zu B of LDS", lds);
+    reserved = true;
+  }
+  const long M = (long)p.B * p.Ho * p.Wo;
+  g_last_variant = 3000 + KS * 10 + NTW;
+  hipLaunchKernelGGL((conv_pwn_kernel<KS, NTW>), dim3((unsigned)((M + 63) / 64), (unsigned)(p.Cout / (128 * NTW))), dim3(512), lds, st, p);
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(pwn): %s", hipGetErrorString(e_));
+  return 1;
+}
+template <typename T>
+static int dispatch_pwn(ConvP p, int ngroup, hipStream_t st) {
+  if constexpr (sizeof(T) != 2) return 0;
+  else {
+    const long M = (long)p.B * p.Ho * p.Wo;
+    if (!tune().pwn || p.k != 1 || p.stride != 1 || ngroup != 1 || M > tune().pwn_max_m || M < 1024 || p.Cout % 128 || p.res || p.addz || p.out_scale != 1.f ||
+        p.vec_store != 2 || (p.bias && !ey_aligned(p.bias, 16)))
+      return 0;
+    int K = 0;
+    for (int s2 = 0; s2 < p.nsrc; ++s2) {
+      if (p.srcC[s2] % 32) return 0;
+      K += p.srcC[s2];
+      const int up = p.srcUp[s2];
+      const long bytes = (((long)p.B * (p.H >> up) * (p.W >> up) - 1) * p.srcCs[s2] + p.srcC[s2]) * 2;
+      if (bytes >= (1L << 31)) return 0;
+      p.srcBytes[s2] = (unsigned)bytes;
+    }
+    if (K < 128 || K > 512 || M * p.yCs * 2 >= (1L << 31)) return 0;
+    p.NTpack = 8;
+    p.Ctot = K;
+    long ntw = tune().pwn_ntw;
+    if (ntw != 1 && ntw != 2) ntw = (p.Cout % 256 == 0 && (M + 63) / 64 >= 192) ? 2 : 1;  // 256-channel slabs once the pixel tiles alone fill the chip
+    if (p.Cout % 256) ntw = 1;
+#define PWN(KSV) if (K == 32 * KSV) return ntw == 2 ? pwn_launch<KSV, 2>(p, st) : pwn_launch<KSV, 1>(p, st);
+    PWN(4) PWN(6) PWN(8) PWN(12) PWN(16)
+#undef PWN
+    return 0;
+  }
+}
+
 // returns 1 if launched, 0 if this shape does not fit the weight-stationary kernel, <0 on error
 template <typename T>
 static int dispatch_ws(ConvP p, int ngroup, hipStream_t st) {
@@ -2391,6 +2550,8 @@ template <typename T>
 static int conv2d_typed(const ConvP& p, int ngroup, hipStream_t st) {
   const int pw = dispatch_pw<T>(p, ngroup, st);
   if (pw != 0) return pw < 0 ? pw : EY_OK;
+  const int pn = dispatch_pwn<T>(p, ngroup, st);
+  if (pn != 0) return pn < 0 ? pn : EY_OK;
   const int pwr = dispatch_pwr<T>(p, ngroup, st);
   if (pwr != 0) return pwr < 0 ? pwr : EY_OK;
   const int sm = dispatch_small<T>(p, ngroup, st);

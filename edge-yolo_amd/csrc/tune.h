@@ -31,6 +31,9 @@ struct EyTune {
   long pw_m = 110000;           // lean pointwise kernel below this many output pixels (0 = off)
   long pw_waves = 3072;         // pw: prefer the widest channel tile that still leaves this many waves
   long pw_wmb = 64;             // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this many MiB
+  long pwn = 1;                 // N-split pointwise kernel (small maps, K 128..512, Cout % 128 == 0; 0 = off)
+  long pwn_max_m = 110000;      // ... up to this many output pixels
+  long pwn_ntw = 0;             // ... developer knob: 16-channel blocks per wave (1, 2; 0 = rule)
   long ds_p = 0;                // dsconv strip kernel: force the strip length (0 = measured rule)
   long tz_kmask = 168;          // Toeplitz dsconv kernel: bit k set = use it for kernel size k (168 = k 3, 5, 7)
   long tz_minpx = 100000;       // ... k = 3/5 only on maps with at least this many pixels (k = 7 always)

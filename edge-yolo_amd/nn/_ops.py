@@ -192,6 +192,8 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
                 rec.kernel = f"conv_pwr_kernel<{tn},{lv % 1000 // 10},{lv % 10}>"
             elif lv >= 4000:
                 rec.kernel = f"conv_pw_kernel<{tn},{lv % 1000 // 10}>"
+            elif lv >= 3000:
+                rec.kernel = f"conv_pwn_kernel<{tn},{lv % 1000 // 10},{lv % 10}>"
         return out
     L.check(L.lib().ey_conv2d(ctypes.byref(d), L.stream()), "ey_conv2d")
     return out
