@@ -67,6 +67,7 @@ SIGNATURES = {
     "ey_conv_packed_bytes": (_sz, [_i, _i, _i, _i]),
     "ey_conv_pack_weight": (_i, [_i, _i, _i, _i, _vp, _vp, _sz]),
     "ey_conv2d": (_i, [C.POINTER(ConvDesc), _vp]),
+    "ey_conv_pw_pair": (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _vp]),
     "ey_conv_variant": (_i, [_i, _i, _i, _i, _i, _i, C.c_long, _i]),
     "ey_conv_last_variant": (_i, []),
     "ey_conv_pack_nt": (_i, [_i]),

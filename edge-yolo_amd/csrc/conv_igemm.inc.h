@@ -1547,6 +1547,91 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p) {
 }
 
 // ================================================================================================================
+// Two chained pointwise convs as ONE launch (f16; maps up to ~50 k pixels): the enhancer tail conv of a DSC3K2_Wavelet block
+// (bias + bilinear-resized pre-activation term + SiLU * tanh(gamma) + residual, conv_epilogue) followed by the stacked cv1|cv2 conv
+// of the DSC3k behind it -- both read and write the same 16 pixels, so a wave runs them back to back: the first conv exactly as
+// conv_pw_kernel (its result is stored: the block's concat and the bottleneck residuals need it), then its own 16 x Cmid outputs come
+// back as the B fragments of the second conv (lane (r, g) wrote channels 4 NT g ..., reads channels 32 s + 8 g ...: a cross-lane move
+// through the just-written lines, ordered by a workgroup-scope release / acquire pair = one s_waitcnt), second conv, plain epilogue.
+// Same k-step order as the two conv_pw_kernel launches: bit-identical.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_pwc_kernel(ConvP p, ConvP q) {
+  typedef f16 T;
+  constexpr int BATCH = NT <= 4 ? 4 : 2;
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int m_tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m_tile >= (int)p.ntile) return;  // whole wave
+  const int M = p.B * p.Ho * p.Wo;
+  const int m = m_tile * 16 + r;
+  const bool pv = m < M;
+  const int hw = p.Ho * p.Wo, mm = pv ? m : 0;
+  const int b = mm / hw, rem = mm - b * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+  const int ch0 = g * 4 * NT;  // one channel tile: NT == NTpack
+  f32x4 acc[NT];
+  {  // ---- first conv
+    const unsigned voff = pv ? (unsigned)((m * p.srcCs[0] + 8 * g) * 2) : EY_OOB;
+    const __amdgpu_buffer_rsrc_t rs = ey_rsrc(p.src[0], p.srcBytes[0]);
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(p.w, (unsigned)(16 * NT * p.Kpad * 2));
+    const unsigned wvoff = (unsigned)((r * p.Kpad + 8 * g) * 2);
+    const int rowblk = 16 * p.Kpad * 2, nsteps = p.srcC[0] >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+    for (int t0 = 0; t0 < nsteps; t0 += BATCH) {
+      Vec8<T> bf[BATCH], af[BATCH][NT];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (t0 + u < nsteps) {
+          const int c = (t0 + u) << 5;
+          BufLoad8<T>::load(bf[u], rs, voff, c * 2);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[u][nt], rw, wvoff, nt * rowblk + c * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (t0 + u < nsteps) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = mma16(af[u][nt], bf[u], acc[nt]);
+        }
+      }
+    }
+    if (pv) conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, 0);
+  }
+  // the 16 x Cmid tile this wave just stored is its own input now, laid out across other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  {  // ---- second conv
+    const unsigned voff = pv ? (unsigned)((m * q.srcCs[0] + 8 * g) * 2) : EY_OOB;
+    const __amdgpu_buffer_rsrc_t rs = ey_rsrc(q.src[0], q.srcBytes[0]);
+    const __amdgpu_buffer_rsrc_t rw = ey_rsrc(q.w, (unsigned)(16 * NT * q.Kpad * 2));
+    const unsigned wvoff = (unsigned)((r * q.Kpad + 8 * g) * 2);
+    const int rowblk = 16 * q.Kpad * 2, nsteps = q.srcC[0] >> 5;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4)0.f;
+    for (int t0 = 0; t0 < nsteps; t0 += BATCH) {
+      Vec8<T> bf[BATCH], af[BATCH][NT];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (t0 + u < nsteps) {
+          const int c = (t0 + u) << 5;
+          BufLoad8<T>::load(bf[u], rs, voff, c * 2);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) BufLoad8<T>::load(af[u][nt], rw, wvoff, nt * rowblk + c * 2);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        if (t0 + u < nsteps) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = mma16(af[u][nt], bf[u], acc[nt]);
+        }
+      }
+    }
+    if (pv) conv_epilogue<T, NT>(q, acc, m, b, oy, ox, ch0, 0);
+  }
+}
+
+// ================================================================================================================
 // Register-stationary pointwise kernel for LARGE maps with few channels (1x1, stride 1, Cin <= 128, <= 2 sources): the whole
 // [16*NT][K] weight tile of a wave is KS*NT MFMA fragments -- it lives in registers for the life of a persistent wave, as
 // does the bias.  A wave then walks 16-pixel tiles: KS buffer loads (next tile's already in flight), KS*NT MFMAs, a short
@@ -2579,7 +2664,7 @@ int ey_conv2d_run_f32(const ConvP& p, int ngroup, hipStream_t st) { return conv2
 #else
 int ey_conv2d_run_f16(const ConvP& p, int ngroup, hipStream_t st) { return conv2d_typed<f16>(p, ngroup, st); }
 
-extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
+static int conv_desc_to_p(const ey_conv_desc* d, ConvP& p, int& ngroup) {
   EY_CHECK(d, "conv: null desc");
   EY_CHECK(d->dtype == EY_F16 || d->dtype == EY_F32, "conv: bad dtype %d", d->dtype);
   const int es = d->dtype == EY_F16 ? 2 : 4;
@@ -2603,9 +2688,8 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   EY_CHECK(d->y_cstride >= d->Cout, "conv: y_cstride %d < Cout %d", d->y_cstride, d->Cout);
   EY_CHECK(!d->res || d->res_cstride >= d->Cout, "conv: res_cstride");
   EY_CHECK(!d->addz || (d->addz_H > 0 && d->addz_W > 0 && d->addz_cstride >= d->Cout), "conv: addz extent/cstride");
-  const int ngroup = d->ngroup > 0 ? d->ngroup : 1;
+  ngroup = d->ngroup > 0 ? d->ngroup : 1;
   EY_CHECK(ngroup == 1 || d->nsrc == 1, "conv: ngroup>1 needs a single source");
-  ConvP p;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.k = d->k; p.stride = d->stride;
   p.pad = d->pad; p.act = d->act; p.nsrc = d->nsrc;
   for (int s = 0; s < 2; ++s) {
@@ -2629,10 +2713,48 @@ extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
   if (p.vec_store && (d->y_cstride * es) % 16 == 0 && ey_aligned(d->y, 16) && (d->y_gstride * es) % 16 == 0 &&
       (!d->res || ((d->res_cstride * es) % 16 == 0 && ey_aligned(d->res, 16))))
     p.vec_store = 2;  // 16-byte epilogue accesses allowed
+  return EY_OK;
+}
+
+extern "C" int ey_conv2d(const ey_conv_desc* d, ey_stream_t stream) {
+  ConvP p;
+  int ngroup = 1;
+  const int rc = conv_desc_to_p(d, p, ngroup);
+  if (rc != EY_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   g_last_variant = 0;
   return d->dtype == EY_F16 ? ey_conv2d_run_f16(p, ngroup, st) : ey_conv2d_run_f32(p, ngroup, st);
 }
+
+// ---- two chained pointwise convs (conv_pwc_kernel): the second reads exactly what the first writes
+extern "C" int ey_conv_pw_pair(const ey_conv_desc* first, const ey_conv_desc* second, ey_stream_t stream) {
+  ConvP p, q;
+  int g1 = 1, g2 = 1;
+  int rc = conv_desc_to_p(first, p, g1);
+  if (rc != EY_OK) return rc;
+  rc = conv_desc_to_p(second, q, g2);
+  if (rc != EY_OK) return rc;
+  const long M = (long)p.B * p.Ho * p.Wo;
+  const int nt = conv_nt(p.Cout);
+  const bool fits = tune().pwc && first->dtype == EY_F16 && second->dtype == EY_F16 && g1 == 1 && g2 == 1 && p.k == 1 && q.k == 1 && p.stride == 1 && q.stride == 1 &&
+                    p.nsrc == 1 && q.nsrc == 1 && !p.srcUp[0] && !q.srcUp[0] && (p.Cout == 64 || p.Cout == 128) && q.Cout == p.Cout && q.srcC[0] == p.Cout &&
+                    p.srcC[0] % 32 == 0 && p.srcC[0] <= 128 && q.src[0] == p.y && q.srcCs[0] == p.yCs && q.B == p.B && q.H == p.Ho && q.W == p.Wo && !q.res && !q.addz &&
+                    q.y != p.y && p.vec_store == 2 && q.vec_store == 2 && M <= tune().pw_m && nt * 16 == p.Cout;
+  if (!fits) return ey_set_error(EY_EUNSUPPORTED, "conv_pw_pair: shapes outside the chained kernel (f16, 1x1 -> 1x1, 64 or 128 channels, small maps)");
+  for (ConvP* c : {&p, &q}) {
+    const long bytes = (((long)c->B * c->H * c->W - 1) * c->srcCs[0] + c->srcC[0]) * 2;
+    if (bytes >= (1L << 31)) return ey_set_error(EY_EUNSUPPORTED, "conv_pw_pair: view larger than 2 GiB");
+    c->srcBytes[0] = (unsigned)bytes;
+    c->NTpack = nt;
+    c->ntile = (M + 15) / 16;
+  }
+  const dim3 grid((unsigned)((p.ntile + 3) / 4));
+  if (nt == 4) hipLaunchKernelGGL((conv_pwc_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+  else hipLaunchKernelGGL((conv_pwc_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+  EY_LAUNCH_CHECK("ey_conv_pw_pair");
+  return EY_OK;
+}
+
 
 // ---- chained pointwise pair (see conv_pw2_kernel)
 extern "C" int ey_conv_chain_kperm(int Cmid, int* perm, int perm_len) {

@@ -91,7 +91,7 @@ def igemm_ok(srcs, k, s, p):
 
 
 def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=None, addz=None, out_scale=1.0,
-           ngroup=1, src_gstride=0, y_gstride=0, group_C=None, w_sets=1):
+           ngroup=1, src_gstride=0, y_gstride=0, group_C=None, w_sets=1, _build_only=False):
     """y = res + out_scale*act(conv(cat(srcs)) + bias + up2x(addz)).  srcs: list of 1-2 logical-NCHW tensors
     (source i is read through a nearest x2 upsample when up[i]).  With ngroup>1 `srcs[0]`/`out` are the group-0
     slices and *_gstride the element offsets between groups (channel count per group = group_C)."""
@@ -113,6 +113,8 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
             raise ValueError(f"conv2d: sources disagree: {[tuple(t.shape) for t in srcs]} up={up}")
     cin = sum(t.shape[1] for t in srcs)
     if len(srcs) > 2 or not igemm_ok(srcs, k, s, p):
+        if _build_only:
+            return None
         _no_block("conv shape outside the MFMA kernel")
         if len(srcs) != 1 or up[0] or addz is not None or ngroup != 1 or out_scale != 1.0:
             raise NotImplementedError("this conv shape needs the generic direct kernel, which takes a single plain source")
@@ -163,6 +165,8 @@ def conv2d(mod, srcs, folded_fn, k, s, p, act, out=None, res=None, tag="", up=No
         d.addz, d.addz_cstride, d.addz_H, d.addz_W = addz.data_ptr(), L.cstride(addz), addz.shape[2], addz.shape[3]
     d.ngroup, d.src_gstride, d.y_gstride = ngroup, src_gstride, y_gstride
     d.w_gstride, d.w_gmax = (wset_elems, w_sets - 1) if w_sets > 1 else (0, 0)
+    if _build_only:  # (descriptor, output, tensors the descriptor points into)
+        return d, out, (srcs, wp, bias, res, addz)
     if RECORD is not None:
         RECORD.conv(d, srcs, up, out, res, addz, wp, bias, 2.0 * ngroup * B * Ho * Wo * cout * cin * k * k, w_sets * cout * cin * k * k * x0.element_size())
         return out
@@ -239,6 +243,30 @@ def conv_pw_chain(mod, x, fold1, act1, fold2, act2, out):
                                          b1.data_ptr() if b1 is not None else None, act1, w2p.data_ptr(), b2.data_ptr() if b2 is not None else None, act2,
                                          out.data_ptr(), L.cstride(out), L.stream()), "ey_conv_pw_chain")
     return out
+
+
+def conv_pw_pair(a, b):
+    """Two chained 1x1 convs as one launch where the shapes allow (ey_conv_pw_pair): `a` / `b` = dict(mod=, folded_fn=, act=, tag=[, srcs=, out=,
+    res=, addz=, out_scale=]); b reads a's output.  Returns (y_a, y_b); y_b is None when only the first conv was run (caller runs b itself)."""
+    first = dict(mod=a["mod"], srcs=a["srcs"], folded_fn=a["folded_fn"], k=1, s=1, p=0, act=a["act"], out=a.get("out"), res=a.get("res"), addz=a.get("addz"),
+                 out_scale=a.get("out_scale", 1.0), tag=a.get("tag", ""))
+    x = a["srcs"][0]
+    if RECORD is None and len(a["srcs"]) == 1 and torch.is_tensor(x) and x.dtype == torch.float16 and x.is_cuda:
+        b1 = conv2d(_build_only=True, **first)
+        if b1 is not None:
+            d1, y1, keep1 = b1
+            b2 = conv2d(b["mod"], [y1], b["folded_fn"], 1, 1, 0, b["act"], out=b.get("out"), tag=b.get("tag", ""), _build_only=True)
+            if b2 is not None:
+                d2, y2, keep2 = b2
+                B, cmid, H, W = y1.shape
+                try:
+                    with _tr(f"conv_pwc_kernel<f16,{cmid // 16}>", _nb(x, y1, y2, a.get("res"), a.get("addz")), 2.0 * B * H * W * cmid * (x.shape[1] + y2.shape[1]),
+                             note=f"{x.shape[1]}->{cmid}->{y2.shape[1]} k1 {H}x{W}"):
+                        L.check(L.lib().ey_conv_pw_pair(ctypes.byref(d1), ctypes.byref(d2), L.stream()), "ey_conv_pw_pair")
+                    return y1, y2
+                except NotImplementedError:  # EY_EUNSUPPORTED: returned before anything is launched
+                    pass
+    return conv2d(**first), None
 
 
 def conv2d_direct(mod, x, folded_fn, k, s, p, g, act, out=None, res=None, tag=""):

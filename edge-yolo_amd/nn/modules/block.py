@@ -114,13 +114,14 @@ class C3(_Packed):
         (w1, b1), (w2, b2) = self.cv1.folded(), self.cv2.folded()
         return torch.cat((w1, w2), 0), torch.cat((b1, b2), 0)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, cv12=None):
+        """cv12 (extension): the stacked cv1|cv2 output when the caller has already computed it (chained into the producer of x)."""
         x = L.as_nhwc(x)
         B, _, H, W = x.shape
         c_ = self.cv1.conv.out_channels
         # buf = [cv1(x) -> m(.) in place | cv2(x)]: the bottleneck chain rewrites slot 0 in place (its last conv reads a
         # temporary and adds slot 0 pixel-by-pixel as the residual), so cat() never happens
-        buf = ops.conv2d(self, [x], self._cv12, 1, 1, 0, L.ACT_SILU, tag="cv12")
+        buf = cv12 if cv12 is not None else ops.conv2d(self, [x], self._cv12, 1, 1, 0, L.ACT_SILU, tag="cv12")
         slot, t, spare = buf[:, :c_], buf[:, :c_], None
         for m in self.m:
             if isinstance(m, DSBottleneck):
@@ -167,7 +168,8 @@ class SPPF(nn.Module):
         self.cv1 = Conv(c1, c_, 1, 1)
         self.cv2 = Conv(c_ * 4, c2, 1, 1)
 
-    def forward(self, x, out=None):
+    def forward(self, x, out=None, cv12=None):
+        """cv12 (extension): the stacked cv1|cv2 output when the caller has already computed it (chained into the producer of x)."""
         x = L.as_nhwc(x)
         B, _, H, W = x.shape
         c_ = self.cv1.conv.out_channels
@@ -419,7 +421,9 @@ class _WaveletEnhancer(_Packed):
             wz[:, i * h:(i + 1) * h] *= bw[i]
         return wz.contiguous(), None
 
-    def forward(self, b, out=None):
+    def forward(self, b, out=None, then=None):
+        """then (extension): dict(mod=, folded_fn=, act=, tag=) of a 1x1 conv that reads this module's output -- where the shapes allow both run as
+        one launch (ops.conv_pw_pair) and (y, y_then) is returned; y_then is None when the caller has to run that conv itself."""
         b = L.as_nhwc(b)
         B, c, H, W = b.shape
         if H < 2 or W < 2:
@@ -431,6 +435,8 @@ class _WaveletEnhancer(_Packed):
         if self.fused_z:  # f16: DWT + the four sub-band convs + Z in ONE kernel, only Z touches HBM
             Z = ops.wavelet_z(self, b, self._subband_sets, self._fuse_z)
             if Z is not None:
+                if then is not None:
+                    return ops.conv_pw_pair(dict(mod=self, srcs=[b], folded_fn=self._fuse_b, act=L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b"), then)
                 return ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")
         sub = ops.dwt_haar(b)  # (B,4c,H/2,W/2): LL|LH|HL|HH
         P = L.empty_nhwc(B, 2 * c, H // 2, W // 2, b.dtype, b.device)
@@ -439,7 +445,8 @@ class _WaveletEnhancer(_Packed):
         ops.conv2d(self, [sub[:, :c]], self._subband_sets, 3, 1, 1, L.ACT_SILU, out=P[:, :h], ngroup=4, src_gstride=c, y_gstride=h, w_sets=2,
                    tag="sub")
         Z = ops.conv2d(self, [P], self._fuse_z, 1, 1, 0, L.ACT_NONE, tag="z")
-        return ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")
+        y = ops.conv2d(self, [b], self._fuse_b, 1, 1, 0, L.ACT_SILU, out=out, res=b, addz=Z, out_scale=g, tag="b")
+        return (y, None) if then is not None else y
 
 
 class DSC3K2_Wavelet(nn.Module):
@@ -466,9 +473,16 @@ class DSC3K2_Wavelet(nn.Module):
         c, n = self.c, len(self.m)
         t = self.cv1(x)  # [a | b]
         buf = L.empty_nhwc(B, (1 + n) * c, H, W, x.dtype, x.device)  # [wave(b) | m_0 | ...]
-        self.wave(t[:, c:], out=_slot(buf, 0, c))
+        pre = None
+        if n and isinstance(self.m[0], C3):  # the DSC3k behind the enhancer starts with a 1x1 over the enhancer's output: chained into its tail conv
+            _, pre = self.wave(t[:, c:], out=_slot(buf, 0, c), then=dict(mod=self.m[0], folded_fn=self.m[0]._cv12, act=L.ACT_SILU, tag="cv12"))
+        else:
+            self.wave(t[:, c:], out=_slot(buf, 0, c))
         for i, m in enumerate(self.m):
-            m(_slot(buf, i, c), out=_slot(buf, 1 + i, c))
+            if i == 0 and pre is not None:
+                m(_slot(buf, i, c), out=_slot(buf, 1 + i, c), cv12=pre)
+            else:
+                m(_slot(buf, i, c), out=_slot(buf, 1 + i, c))
         # cat(a, wave(b), m...) is never built: cv2 reads the two buffers as one virtual concat
         if tail is not None:
             y = ops.pw_conv3s2(self.cv2, tail, [t[:, :c], buf])

@@ -133,6 +133,12 @@ int ey_conv2d_direct(const ey_conv_direct_desc* d, ey_stream_t stream);
 int ey_stem_conv(int x_dtype, int y_dtype, int B, int Cin, int H, int W, int Cout, int act, const void* x_nchw,
                  const float* w_oihw, const float* bias, void* y, int y_cstride, ey_stream_t stream);
 
+/* ---- two chained 1x1 convs as one launch (f16, 64 or 128 channels, small maps): `second` must read exactly what `first` writes
+ * (second->src[0] == first->y, same cstride, one source each; `first` may carry bias / addz / activation / out_scale / residual, `second`
+ * bias / activation).  Built for the _WaveletEnhancer tail conv (block.py:3700-3710) + the stacked cv1|cv2 conv of the DSC3k behind it
+ * (block.py:382-396).  Both outputs are written; bit-identical to two ey_conv2d calls.  EY_EUNSUPPORTED (nothing launched) otherwise. */
+int ey_conv_pw_pair(const ey_conv_desc* first, const ey_conv_desc* second, ey_stream_t stream);
+
 /* ---- a block's closing 1x1 conv over a two-part virtual concat + the stride-2 3x3 conv behind it, as one kernel (f16; Cmid = Cout = 64;
  * C0, C1 <= 32, multiples of 8; both bias + SiLU):   y = act2( Conv3x3s2( act1( Conv1x1( cat(src0, src1) ) + bias1 ) ) + bias2 )
  * = DSC3K2_Wavelet.cv2 / C2f.cv2 (block.py:357-396,3783-3788) + the next backbone layer Conv(64,64,3,2) (conv.py:41-59).  The (B,64,H,W)
