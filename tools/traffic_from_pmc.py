@@ -21,6 +21,19 @@ def label_of(name):
     m = re.search(r"conv_ws_kernelIDF16_Li(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         return f"conv_ws_kernel<f16,{m[1]},{m[2]},{m[3]}>"
+    m = re.search(r"conv_pwn_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"conv_pwn_kernel<(\d+), (\d+)>", name)
+    if m:
+        return f"conv_pwn_kernel<f16,{m[1]},{m[2]}>"
+    m = re.search(r"conv_pwc_kernelILi(\d+)E", name) or re.search(r"conv_pwc_kernel<(\d+)>", name)
+    if m:
+        return f"conv_pwc_kernel<f16,{m[1]}>"
+    m = re.search(r"dsb_pair_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"dsb_pair_kernel<(\d+), (\d+)", name)
+    if m:
+        return f"dsb_pair_kernel<{m[1]},{m[2]}>"
+    if "stem_pair_kernel" in name:
+        return "stem_pair_kernel"
+    if "pw3b_kernel" in name or "pw3_kernel" in name:
+        return "pw3_kernel"
     m = re.search(r"conv_pwr_kernelIDF16_Li(\d+)ELi(\d+)E", name)
     if m:
         return f"conv_pwr_kernel<f16,{m[1]},{m[2]}>"
