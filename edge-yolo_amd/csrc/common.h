@@ -48,6 +48,16 @@ static inline int ey_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // hardware barrier itself does not drain them); registers loaded from global memory are still waited for at their first use.
 __device__ __forceinline__ void ey_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2; MI355X_MICROARCH.md, speed only -- nothing here
+// depends on it for correctness).  Kernels whose neighbouring blocks read overlapping input (stencil halos, window rows) take their work
+// item from this permutation of the block index instead: every XCD then owns ONE contiguous range of the work list, and the shared
+// lines are fetched into one L2 instead of two or three (measured, profiles/r03_pmc_traffic.json: 1.66-2.06x the algorithmic bytes
+// with the plain index).
+__device__ __forceinline__ unsigned ey_xcd_block(unsigned b, unsigned nb) {
+  const unsigned q = nb >> 3, rem = nb & 7u, x = b & 7u, i = b >> 3;
+  return x < rem ? x * (q + 1) + i : rem * (q + 1) + (x - rem) * q + i;
+}
+
 // ---- element <-> float
 __device__ __forceinline__ float to_f(f16 v) { return (float)v; }
 __device__ __forceinline__ float to_f(float v) { return v; }

@@ -304,10 +304,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(int B, int H, int W, int C,
 // weight vectors and the bias live in registers, and every loaded vector feeds up to 3 outputs per row: 18 loads and
 // (for f16) 288 v_fma_mix per 4 outputs instead of 36 loads + per-tap address arithmetic + 72 conversions per output.
 template <typename T, int P>
-__global__ __launch_bounds__(256) void dwconv3_strip_kernel(int B, int H, int W, int C, int act, const T* __restrict__ x, int xCs, unsigned xBytes,
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(int B, int H, int W, int C, int act, int xcd, const T* __restrict__ x, int xCs, unsigned xBytes,
                                                             const T* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int yCs) {
   const int cv = C >> 3, WS = (W + P - 1) / P;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int idx = (int)(xcd ? ey_xcd_block(blockIdx.x, gridDim.x) : blockIdx.x) * 256 + threadIdx.x;  // neighbouring rows' strips in one XCD's L2
   if (idx >= B * H * WS * cv) return;
   const int c8 = (idx % cv) * 8;
   int t = idx / cv;
@@ -363,7 +363,7 @@ static int dw_launch(int B, int H, int W, int C, int k, int act, const void* x, 
   if (k == 3 && xbytes < (1L << 31) && total < (1L << 31)) {
     constexpr int P = sizeof(T) == 2 ? 4 : 2;
     const long n = (long)B * H * ((W + P - 1) / P) * (C / 8);
-    hipLaunchKernelGGL((dwconv3_strip_kernel<T, P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, H, W, C, act, (const T*)x, xCs, (unsigned)xbytes,
+    hipLaunchKernelGGL((dwconv3_strip_kernel<T, P>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, B, H, W, C, act, (int)(tune().xcd_map & 1), (const T*)x, xCs, (unsigned)xbytes,
                        (const T*)w, bias, (T*)y, yCs);
     EY_LAUNCH_CHECK("ey_dwconv");
     return EY_OK;

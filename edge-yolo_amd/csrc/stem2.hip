@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void stem_pair_kernel(int B, int H, int W, int
   f16* s_st = s_in + 3 * IR * LW;            // [SR][SW][ST2_SP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, g = lane >> 4;
   const int tilesX = (Wo + TW - 1) / TW, tilesY = (Ho + TH - 1) / TH;
-  const int b = blockIdx.x / (tilesX * tilesY), trem = blockIdx.x - b * (tilesX * tilesY);
+  const int bid = (int)ey_xcd_block(blockIdx.x, gridDim.x);  // neighbouring tiles (shared patch rows / columns) in one XCD's L2
+  const int b = bid / (tilesX * tilesY), trem = bid - b * (tilesX * tilesY);
   const int oy0 = (trem / tilesX) * TH, ox0 = (trem % tilesX) * TW;
   const int iy0 = 4 * oy0 - 3, ixa = 4 * ox0 - 8;  // first staged input row / (8-aligned) column
   // ---- A. input patch
