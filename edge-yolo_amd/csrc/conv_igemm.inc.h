@@ -42,6 +42,7 @@ struct ConvP {
   int ntn;       // number of channel tiles (small-M kernel)
   int vec_store; // 1: y/res/addz views are aligned for 4-element vector access
   int tTR, tTC;  // stride-1 3x3 tile kernel: output tile rows x columns (tTR*tTC <= 256 pixels, (tTR+2)*(tTC+2) <= 340 halo pixels)
+  int xcd;       // 3x3 stream / tile kernels: XCD-contiguous work order (ey_xcd_block)
 };
 
 __device__ __forceinline__ f32x4 mma16(const Vec8<f16>& a, const Vec8<f16>& b, f32x4 c) {
@@ -781,7 +782,8 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(ConvP p) {
   const int hHR = (S == 1) ? tTR + 2 : HR, hHC = (S == 1) ? tTC + 2 : HC, lrow = (S == 1) ? hHC : LROW;
   const float inv_hc = 1.0f / (float)hHC, inv_tc = 1.0f / (float)tTC;
   const int tilesX = (p.Wo + tTC - 1) / tTC, tilesY = (p.Ho + tTR - 1) / tTR, tiles_img = tilesX * tilesY;
-  const int b = blockIdx.x / tiles_img, trem = blockIdx.x - b * tiles_img;
+  const int bid = p.xcd ? (int)ey_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // neighbouring tiles (shared halos) in one XCD's L2
+  const int b = bid / tiles_img, trem = bid - b * tiles_img;
   const int oy0 = (trem / tilesX) * tTR, ox0 = (trem % tilesX) * tTC;
   const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int Cin = p.srcC[0];
@@ -1248,8 +1250,9 @@ __global__ __launch_bounds__(512, 2) void conv3s_kernel(ConvP p) {
   };
 
   // workgroup b owns tiles [b * tpw, (b + 1) * tpw); wave w takes b * tpw + w, + 8, ...
-  const long tpw = (p.ntile + gridDim.x - 1) / gridDim.x, tend = min(p.ntile, (long)(blockIdx.x + 1) * tpw);
-  long tile = (long)blockIdx.x * tpw + wave;
+  const long lb = p.xcd ? ey_xcd_block(blockIdx.x, gridDim.x) : blockIdx.x;  // the runs of one XCD's workgroups are contiguous: shared window rows in one L2
+  const long tpw = (p.ntile + gridDim.x - 1) / gridDim.x, tend = min(p.ntile, (lb + 1) * tpw);
+  long tile = lb * tpw + wave;
   if (tile >= tend) return;
   Desc cur, nxt;
   setup(tile, cur);
@@ -2141,6 +2144,7 @@ static int tile_launch(ConvP p, int ngroup, hipStream_t st) {
   p.tTR = tr; p.tTC = tc;
   const long tiles = (long)p.B * ((p.Wo + tc - 1) / tc) * ((p.Ho + tr - 1) / tr);
   const dim3 grid((unsigned)tiles, (unsigned)(conv_cout_pad(p.Cout) / (16 * NT)), (unsigned)ngroup);
+  p.xcd = (int)((tune().xcd_map >> 4) & 1) && grid.y == 1 && grid.z == 1;  // (x alone decides the XCD only for a 1-D grid)
   static bool attr = false;
   if (!attr) {  // up to 46 + 46 KB of dynamic LDS
     (void)hipFuncSetAttribute((const void*)conv3_tile_kernel<T, NT, S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -2300,6 +2304,7 @@ static int c3s_launch2(ConvP p, hipStream_t st) {
   long gx = 256 / ny;  // one workgroup per CU over all channel tiles
   if (gx < 1) gx = 1;
   if (gx * 8 > p.ntile) gx = (p.ntile + 7) / 8;
+  p.xcd = (int)((tune().xcd_map >> 3) & 1) && (ny == 1 || gx % 8 == 0);
   hipLaunchKernelGGL((conv3s_kernel<NT, MT, UPT, S, NB>), dim3((unsigned)gx, (unsigned)ny, 1), dim3(512), lds, st, p);
   hipError_t e_ = hipGetLastError();
   if (e_ != hipSuccess) return ey_set_error(EY_ELAUNCH, "ey_conv2d(c3s): %s", hipGetErrorString(e_));
@@ -2703,6 +2708,7 @@ static int conv_desc_to_p(const ey_conv_desc* d, ConvP& p, int& ngroup) {
   p.zsy = d->addz ? (float)d->addz_H / (float)d->Ho : 0.f; p.zsx = d->addz ? (float)d->addz_W / (float)d->Wo : 0.f; p.srcG = d->src_gstride; p.yG = d->y_gstride;
   p.wG = d->w_gstride; p.wGmax = d->w_gmax > 0 ? d->w_gmax : 0;
   p.Kpad = conv_kpad(Cin, d->k, es);
+  p.xcd = 0;
   p.nchunks = 0;
   for (int s2 = 0; s2 < d->nsrc; ++s2) p.nchunks += (d->src_C[s2] + CONV_CH - 1) / CONV_CH;
   p.nchunks *= d->k * d->k;

@@ -10,6 +10,7 @@
 // sub-bands (with the 3x3 halo, zero outside the map = the conv's padding) and P in LDS, and writes only Z.  Same rounding points
 // as the unfused f16 path (sub-bands and P are f16 tensors there too), fp32 accumulation, the K order of ey_conv2d.
 #include "common.h"
+#include "tune.h"
 
 struct WzP {
   int B, H, W, Ho, Wo;
@@ -19,6 +20,7 @@ struct WzP {
   const f16* w_z;                 // packed 1x1 [c][2c]
   f16* z; int zCs;
   int tiles_x, tiles_y;
+  int xcd;  // XCD-contiguous tile order (ey_xcd_block)
 };
 
 __host__ __device__ constexpr int wz_nt(int cout) { return cout <= 16 ? 1 : cout <= 32 ? 2 : cout <= 64 ? 4 : cout <= 80 ? 5 : 8; }
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256 * NS) void wavelet_z_kernel(WzP p) {
   f16* S = reinterpret_cast<f16*>(smem);   // [4][NPOS][SS]
   f16* P = S + 4 * NPOS * SS;               // [TH*16][PS]
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, ns = tid >> 8, r = lane & 15, g = lane >> 4;
-  int blk = blockIdx.x;
+  int blk = p.xcd ? (int)ey_xcd_block(blockIdx.x, gridDim.x) : (int)blockIdx.x;  // neighbouring tiles (shared halo patches) in one XCD's L2
   const int tx = blk % p.tiles_x;
   blk /= p.tiles_x;
   const int ty = blk % p.tiles_y, b = blk / p.tiles_y;
@@ -244,6 +246,7 @@ static int wz_launch(WzP p, hipStream_t st) {
   p.tiles_y = (p.Ho + TH - 1) / TH;
   const long nblk = (long)p.B * p.tiles_x * p.tiles_y;
   if (nblk >= (1L << 31)) return ey_set_error(EY_EINVAL, "wavelet_z: too many tiles");
+  p.xcd = (int)((tune().xcd_map >> 2) & 1);
   hipLaunchKernelGGL((wavelet_z_kernel<C, TH, NS, GS>), dim3((unsigned)nblk), dim3(256 * NS), lds, st, p);
   EY_LAUNCH_CHECK("ey_wavelet_z");
   return EY_OK;
