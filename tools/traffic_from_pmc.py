@@ -30,6 +30,10 @@ def label_of(name):
     m = re.search(r"dsb_pair_kernelILi(\d+)ELi(\d+)E", name) or re.search(r"dsb_pair_kernel<(\d+), (\d+)", name)
     if m:
         return f"dsb_pair_kernel<{m[1]},{m[2]}>"
+    if "wavelet_z_kernel" in name:
+        return "wavelet_z_kernel"
+    if "block_tile_kernel" in name:
+        return "block_tile_kernel"
     if "stem_pair_kernel" in name:
         return "stem_pair_kernel"
     if "pw3b_kernel" in name or "pw3_kernel" in name:
