@@ -12,6 +12,7 @@
 // Arithmetic = stem_mfma_kernel followed by conv3r_kernel, operation for operation: bit-identical to the two-launch form.
 #include "common.h"
 #include "tune.h"
+#include <type_traits>
 
 typedef f16 f16x4v __attribute__((ext_vector_type(4)));
 #define ST2_SP 20  // pitch (halves) of a stem pixel's 16 channels in LDS: 40 B
@@ -20,7 +21,7 @@ __global__ __launch_bounds__(256) void stem_pair_kernel(int B, int H, int W, int
                                                         const float* __restrict__ w0, const float* __restrict__ bias0, const f16* __restrict__ w1, int Kpad1,
                                                         const float* __restrict__ bias1, f16* __restrict__ y, int yCs) {
   constexpr int IR = 4 * TH + 3, IV = (4 * TW + 8) / 8, LW = 4 * TW + 16, NV = 3 * IR * IV;  // input patch: rows, 16-byte vectors per row, LDS row pitch
-  constexpr int SR = 2 * TH + 1, SW = 2 * TW + 1, NS = SR * SW;                              // stem tile
+  constexpr int SR = 2 * TH + 1, SW = 2 * TW + 1;                                            // stem tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f16* s_in = reinterpret_cast<f16*>(smem);  // [3][IR][LW]
   f16* s_st = s_in + 3 * IR * LW;            // [SR][SW][ST2_SP]
@@ -63,26 +64,55 @@ __global__ __launch_bounds__(256) void stem_pair_kernel(int B, int H, int W, int
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) a1[tap][nt] = *reinterpret_cast<const f16x4v*>(w1 + (nt * 16 + r) * Kpad1 + tap * 16 + 4 * g);
   __syncthreads();
-  // ---- B. stem pixels of the tile (flattened, 16 per MFMA)
-  constexpr int NB0 = (NS + 15) / 16, NIT0 = (NB0 + 3) / 4;
-#pragma unroll
-  for (int it = 0; it < NIT0; ++it) {  // (fully unrolled, no branch: the gathers of block i + 1 run under the epilogue of block i; a wave past
-    const int blk = wave + 4 * it;     //  the last block recomputes it and stores nothing)
-    const int pi = blk * 16 + r, pc = pi < NS ? pi : NS - 1;
-    const int t = pc / SW, u = pc - t * SW;
-    const f16* bp = s_in + (2 * t) * LW + 2 * u + 5;
+  // ---- B. stem pixels of the tile, 16 per MFMA.  Blocks = 16-pixel row segments (SR rows x NSEG segments) + the last column as
+  // ceil(SR / 16) column blocks; block id = wave + 4 it, so a wave's segments sit at a FIXED row stride: the 8 gather addresses of a lane
+  // and its store address are bases + compile-time offsets (LDS immediates: no address arithmetic inside the unrolled loop).  Tiles whose
+  // stem pixels all lie inside the stem map (all but the border tiles) skip the padding mask.
+  constexpr int NSEG = TW / 8, RPI = 4 / NSEG, NRS = SR * NSEG, NFULL = NRS / 4, NB0 = NRS + (SR + 15) / 16, NIT0 = (NB0 + 3) / 4;
+  static_assert(NSEG == 2 || NSEG == 4, "TW must be 16 or 32");
+  const bool interior = 2 * oy0 - 1 >= 0 && 2 * oy0 - 1 + SR <= Hs && 2 * ox0 - 1 >= 0 && 2 * ox0 - 1 + SW <= Ws;  // (workgroup-uniform)
+  auto stem_block = [&](const f16* const (&gp)[8], int goff, f16* dst, int row, int col, bool store, auto masked) {
     Vec8<f16> bq;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) bq.v[q] = bp[off[q]];
+    for (int q = 0; q < 8; ++q) bq.v[q] = gp[q][goff];
     const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0.v, bq.v, (f32x4)0.f, 0, 0, 0);
     float v4[4] = {acc[0] + bs0[0], acc[1] + bs0[1], acc[2] + bs0[2], acc[3] + bs0[3]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) v4[j] = ey_silu_rn(v4[j]);
-    const int sy = 2 * oy0 - 1 + t, sx = 2 * ox0 - 1 + u;
-    const bool in = sy >= 0 && sy < Hs && sx >= 0 && sx < Ws;
-    const f16x4v o = {(f16)(in ? v4[0] : 0.f), (f16)(in ? v4[1] : 0.f), (f16)(in ? v4[2] : 0.f), (f16)(in ? v4[3] : 0.f)};
-    if (pi < NS) *reinterpret_cast<f16x4v*>(s_st + pc * ST2_SP + 4 * g) = o;
-  }
+    f16x4v o = {(f16)v4[0], (f16)v4[1], (f16)v4[2], (f16)v4[3]};
+    if constexpr (decltype(masked)::value) {  // stem pixels outside the stem map are layer 1's zero padding
+      const int sy = 2 * oy0 - 1 + row, sx = 2 * ox0 - 1 + col;
+      if (!(sy >= 0 && sy < Hs && sx >= 0 && sx < Ws)) o = (f16x4v)(f16)0.f;
+    }
+    if (store) *reinterpret_cast<f16x4v*>(dst) = o;
+  };
+  auto stem_phase = [&](auto masked) {
+    {  // full iterations: every wave has a row segment
+      const int row0 = wave / NSEG, col0 = (wave % NSEG) * 16 + r;
+      const f16* gp[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gp[q] = s_in + (2 * row0) * LW + 2 * col0 + 5 + off[q];
+      f16* sp0 = s_st + (row0 * SW + col0) * ST2_SP + 4 * g;
+#pragma unroll
+      for (int it = 0; it < NFULL; ++it) stem_block(gp, it * (2 * RPI * LW), sp0 + it * (RPI * SW * ST2_SP), row0 + it * RPI, col0, true, masked);
+    }
+#pragma unroll
+    for (int it = NFULL; it < NIT0; ++it) {  // the last row segments and the column blocks: per-lane coordinates
+      const int id = wave + 4 * it;
+      if (id >= NB0) break;  // (wave-uniform)
+      int row, col;
+      if (id < NRS) { row = id / NSEG; col = (id % NSEG) * 16 + r; }
+      else { row = (id - NRS) * 16 + r; col = 2 * TW; }
+      const bool valid = row < SR;
+      row = valid ? row : SR - 1;
+      const f16* gp[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) gp[q] = s_in + (2 * row) * LW + 2 * col + 5 + off[q];
+      stem_block(gp, 0, s_st + (row * SW + col) * ST2_SP + 4 * g, row, col, valid, masked);
+    }
+  };
+  if (interior) stem_phase(std::false_type{});
+  else stem_phase(std::true_type{});
   __syncthreads();
   // ---- C. layer 1: 16-pixel row segments of the tile
   const int ch0 = g * 4 * NT1;
