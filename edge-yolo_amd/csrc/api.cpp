@@ -25,7 +25,7 @@ EyTune g_ey_tune;
 static const struct { const char* name; size_t off; } k_tunables[] = {
     EY_T(tiles_per_wave), EY_T(mt2_min_m), EY_T(small_m), EY_T(small_wmb), EY_T(halo_min_c), EY_T(ws_lds_kb), EY_T(ws_wg_cu), EY_T(ws_k3_minnt), EY_T(tile_wlds),
     EY_T(tile_s2_minc), EY_T(tile_s2_minm), EY_T(grid_div), EY_T(c3r), EY_T(tile_minwg), EY_T(tile_flat), EY_T(tile_mink), EY_T(pwr_m), EY_T(pwr_frags), EY_T(pw_m),
-    EY_T(pw_waves), EY_T(pw_wmb), EY_T(ds_p), EY_T(tz_kmask), EY_T(tz_minpx), EY_T(ds_strip), EY_T(stem_mfma), EY_T(linattn_mfma), EY_T(softattn_mfma), EY_T(c3p), EY_T(c3p_min_m), EY_T(c3p_fast), EY_T(c3s), EY_T(c3s_mt4_m), EY_T(c3s_min_work), EY_T(c3s_cfg), EY_T(nms_fast_k), EY_T(nms_mask_wg), EY_T(sppf_min_wg), EY_T(sppf_cv), EY_T(dsb_pair), EY_T(dsb_max_px), EY_T(dsb_rb), EY_T(dsb_fixed), EY_T(dsb_p2), EY_T(stem_pair), EY_T(pw3), EY_T(pw3_min_px), EY_T(pw3_skew), EY_T(pwn), EY_T(pwn_max_m), EY_T(pwn_ntw), EY_T(pwc), EY_T(xcd_map)};
+    EY_T(pw_waves), EY_T(pw_wmb), EY_T(ds_p), EY_T(tz_kmask), EY_T(tz_minpx), EY_T(ds_strip), EY_T(stem_mfma), EY_T(linattn_mfma), EY_T(softattn_mfma), EY_T(c3p), EY_T(c3p_min_m), EY_T(c3p_fast), EY_T(c3s), EY_T(c3s_mt4_m), EY_T(c3s_min_work), EY_T(c3s_cfg), EY_T(nms_fast_k), EY_T(nms_mask_wg), EY_T(sppf_min_wg), EY_T(sppf_cv), EY_T(dsb_pair), EY_T(dsb_max_px), EY_T(dsb_rb), EY_T(dsb_fixed), EY_T(dsb_p2), EY_T(stem_pair), EY_T(pw3), EY_T(pw3_min_px), EY_T(pw3_skew), EY_T(pwn), EY_T(pwn_max_m), EY_T(pwn_ntw), EY_T(pwc), EY_T(xcd_map), EY_T(nms_mask_k)};
 static long* tunable(const char* name) {
   if (!name) return nullptr;
   for (const auto& t : k_tunables)

@@ -889,16 +889,20 @@ static int nms_select_launch(int B, int nc, int A, long P, long nkeys, int multi
       hipLaunchKernelGGL(nf_select_kernel<0>, dim3(B), dim3(1024), 0, st, nc, A, P, nkeys, boxsrc, img_stride, max_nms, max_wh, agnostic, K, keys, cls_id, fast_scratch, ib);
     EY_LAUNCH_CHECK("ey_nms(select)");
     const float band = iou_thres >= 1e-6f ? (float)((double)iou_thres * 1e-6) : INFINITY;
+    // bit matrix over the first nms_mask_k candidates only (a multiple of 512); the resolve kernel tests later ones against the kept boxes on the fly
+    long mk = tune().nms_mask_k;
+    if (mk <= 0 || mk > NF_KMAX) mk = NF_KMAX;
+    const int nbm = (int)((mk + 511) / 512) * 8;
     const long mwg = tune().nms_mask_wg > 0 ? tune().nms_mask_wg : NF_MASK_WG;
     hipLaunchKernelGGL(nf_mask_kernel, dim3((unsigned)mwg, B), dim3(256), 0, st, iou_thres, band, (const float4*)(fast_scratch + (size_t)NF_KMAX * 8),
                        (const float*)(fast_scratch + (size_t)NF_KMAX * 24), (const NfMeta*)(fast_scratch + (size_t)NF_KMAX * 28 + (size_t)NF_TILES * 512),
-                       (unsigned long long*)(fast_scratch + (size_t)NF_KMAX * 28), ib);
+                       (unsigned long long*)(fast_scratch + (size_t)NF_KMAX * 28), ib, nbm);
     EY_LAUNCH_CHECK("ey_nms(mask)");
     const size_t lds = lds_general > sizeof(NfResShared) ? lds_general : sizeof(NfResShared);
     if (lds > 60 * 1024 && hipFuncSetAttribute((const void*)nf_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ey_set_error(EY_ELAUNCH, "nms: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL(nf_resolve_kernel, dim3(B), dim3(1024), lds, st, nc, A, P, nkeys, boxsrc, img_stride, iou_thres, max_det, max_nms, max_wh, agnostic, target, cap, partition,
-                       keys, cls_id, fast_scratch, ib, out_boxes, out_count, out_index);
+                       keys, cls_id, fast_scratch, ib, out_boxes, out_count, out_index, nbm);
     EY_LAUNCH_CHECK("ey_nms(resolve)");
     return EY_OK;
   }

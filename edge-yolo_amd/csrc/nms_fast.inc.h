@@ -304,11 +304,11 @@ __device__ __forceinline__ float nf_readlane(float v, int lane) { return __built
 // band = 1e-6 * thr the comparison `fl(inter / union) > thr` is already decided.  (thr < 1e-6: band = inf, always the division.)
 #define NF_MASK_WG 64
 __global__ __launch_bounds__(256) void nf_mask_kernel(float thr, float band, const float4* __restrict__ cbox_all, const float* __restrict__ area_all,
-                                                      const NfMeta* __restrict__ meta_all, unsigned long long* __restrict__ mask_all, size_t img_bytes) {
+                                                      const NfMeta* __restrict__ meta_all, unsigned long long* __restrict__ mask_all, size_t img_bytes, int nbm) {
   __shared__ unsigned part[2][4][64];
   const size_t ioff = (size_t)blockIdx.y * img_bytes;
   const int nsel = reinterpret_cast<const NfMeta*>(reinterpret_cast<const char*>(meta_all) + ioff)->n_sel;
-  const int NB = (nsel + 63) >> 6, ntiles = NB * (NB + 1) / 2;
+  const int NBall = (nsel + 63) >> 6, NB = NBall < nbm ? NBall : nbm, ntiles = NB * (NB + 1) / 2;  // only the first nbm column blocks get a bit matrix (see nf_resolve_kernel)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const float4* __restrict__ cbox = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(cbox_all) + ioff);
   const float* __restrict__ carea = reinterpret_cast<const float*>(reinterpret_cast<const char*>(area_all) + ioff);
@@ -374,8 +374,18 @@ __global__ __launch_bounds__(256) void nf_mask_kernel(float thr, float band, con
   }
 }
 
+struct NfResTail {  // the on-the-fly part (column blocks beyond the bit matrix): shares the 32 KB of `buf`
+  float4 kbox[1024];                 // class-offset boxes of the kept candidates so far, in kept order (max_det <= 1024 on the fast path)
+  float karea[1024];
+  float4 bbox[64];                   // the current block's candidates
+  float barea[64];
+  unsigned long long dg[16][64];     // per wave: 4 rows of the block's own 64 x 64 suppression tile
+};
 struct NfResShared {
-  unsigned long long buf[8][8][64];  // the mask words among the 8 column blocks in flight: [c][rb - cb0] (32 KB)
+  union {
+    unsigned long long buf[8][8][64];  // the mask words among the 8 column blocks in flight: [c][rb - cb0] (32 KB)
+    NfResTail tail;
+  };
   unsigned long long hit[16][64];    // phase A: per wave, "an earlier kept box (of an earlier group of 8 blocks) overlaps me"
   unsigned long long kw[NF_NB];      // kept bits per column block
   int kpre[NF_NB + 1];               // kept boxes before each block
@@ -387,8 +397,9 @@ struct NfResShared {
 __global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P, long nkeys, const float* __restrict__ boxsrc, long img_stride, float iou_thres, int max_det,
                                                           int max_nms, float max_wh, int agnostic, int target, int cap, int partition,
                                                           const unsigned long long* __restrict__ gkeys, const int* __restrict__ cls_id, char* __restrict__ scratch,
-                                                          size_t img_bytes, float* __restrict__ out_boxes, int* __restrict__ out_count, int* __restrict__ out_index) {
+                                                          size_t img_bytes, float* __restrict__ out_boxes, int* __restrict__ out_count, int* __restrict__ out_index, int nbm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(sizeof(NfResTail) <= sizeof(unsigned long long) * 8 * 8 * 64, "the tail state must fit the mask-word buffer");
   NfResShared& S = *reinterpret_cast<NfResShared*>(smem);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   char* img = scratch + (size_t)b * img_bytes;
@@ -399,8 +410,9 @@ __global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P,
   if (tid < NF_NB) S.kw[tid] = 0ull;
   if (tid == 0) { S.nkept = 0; S.stop = 0; }
   __syncthreads();
-  for (int cb0 = 0; cb0 < NB; cb0 += 8) {
-    const int ncb = min(8, NB - cb0);
+  const int NBm = NB < nbm ? NB : nbm;  // column blocks covered by the bit matrix (nbm is a multiple of 8)
+  for (int cb0 = 0; cb0 < NBm; cb0 += 8) {
+    const int ncb = min(8, NBm - cb0);
     {
       // phase A (all 16 waves): the kept-words of every EARLIER group of 8 blocks are final -- waves (c, c + 8) fold the words
       // (cb0 + c, rb < cb0) against them straight from memory (independent loads), half of the row blocks each
@@ -442,6 +454,78 @@ __global__ __launch_bounds__(1024) void nf_resolve_kernel(int nc, int A, long P,
     }
     __syncthreads();
     if (S.stop) break;
+  }
+  // ---- column blocks beyond the bit matrix (only when the first nbm * 64 candidates did not yield max_det boxes): a candidate is tested
+  // against the KEPT boxes only (<= max_det of them, not against every earlier candidate) and against its own block, on the fly, with the
+  // reference's expression itself (the decision the bit matrix encodes: fl(inter / union) > thr) -- a few thousand divisions per block
+  if (!S.stop && NB > NBm) {  // (workgroup-uniform)
+    NfResTail& T = S.tail;
+    const float4* cbox = nf_cbox(img);
+    const float* carea = nf_area(img);
+    if (tid == 0) {
+      int run = 0;
+      for (int cb = 0; cb < NBm; ++cb) { S.kpre[cb] = run; run += __popcll(S.kw[cb]); }
+    }
+    __syncthreads();
+    for (int e = tid; e < NBm * 64; e += 1024) {
+      const unsigned long long w = S.kw[e >> 6];
+      if ((w >> (e & 63)) & 1ull) {
+        const int rank = S.kpre[e >> 6] + __popcll(w & ((1ull << (e & 63)) - 1ull));
+        T.kbox[rank] = cbox[e];
+        T.karea[rank] = carea[e];
+      }
+    }
+    auto hits = [&](const float4& a, float aa, const float4& bx, float ab) {
+      const float w = fmaxf(0.f, __fsub_rn(fminf(a.z, bx.z), fmaxf(a.x, bx.x)));
+      const float h = fmaxf(0.f, __fsub_rn(fminf(a.w, bx.w), fmaxf(a.y, bx.y)));
+      const float inter = __fmul_rn(w, h), uni = __fsub_rn(__fadd_rn(aa, ab), inter);
+      return __fdiv_rn(inter, uni) > iou_thres;
+    };
+    for (int cb = NBm; cb < NB; ++cb) {
+      const int j = cb * 64 + lane;
+      const bool valid = j < nsel;
+      const float4 me = valid ? cbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float marea = valid ? carea[j] : 1.f;
+      if (wave == 0) { T.bbox[lane] = me; T.barea[lane] = marea; }
+      __syncthreads();  // kept list (first pass: gathered above; later: appended by wave 0) and this block's boxes are visible
+      const int nk = S.nkept;
+      bool hit = false;
+      for (int k = wave; k < nk; k += 16) hit = hit || hits(T.kbox[k], T.karea[k], me, marea);
+      S.hit[wave][lane] = hit ? 1ull : 0ull;
+      unsigned long long rows = 0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        if (r < lane && hits(T.bbox[r], T.barea[r], me, marea)) rows |= 1ull << r;  // only EARLIER candidates of the block count
+      }
+      T.dg[wave][lane] = rows;
+      __syncthreads();
+      if (wave == 0) {
+        unsigned long long h2 = 0ull, word = 0ull;
+#pragma unroll
+        for (int w2 = 0; w2 < 16; ++w2) { h2 |= S.hit[w2][lane]; word |= T.dg[w2][lane]; }
+        const bool alive = valid && h2 == 0ull;
+        unsigned long long km = nms_resolve(word, alive);
+        const int room = max_det - nk;
+        if (__popcll(km) > room) {
+          unsigned long long t = km;
+          for (int r = 0; r < room; ++r) t &= t - 1ull;
+          km ^= t;
+        }
+        if ((km >> lane) & 1ull) {  // append to the kept list
+          const int pos = nk + __popcll(km & ((1ull << lane) - 1ull));
+          T.kbox[pos] = me;
+          T.karea[pos] = marea;
+        }
+        if (lane == 0) {
+          S.kw[cb] = km;
+          S.nkept = nk + __popcll(km);
+          S.stop = S.nkept >= max_det;
+        }
+      }
+      __syncthreads();
+      if (S.stop) break;
+    }
   }
   // kept boxes before each block (kw = 0 for blocks the loop never reached)
   if (tid == 0) {

@@ -55,6 +55,7 @@ struct EyTune {
   long sppf_min_wg = 128;       // SPPF pooling: shrink the channel group until at least this many workgroups are launched
   long sppf_cv = 0;             // ... developer knob: force 8-channel vectors per workgroup (1, 2, 4, 8); 0 = the rule
   long nms_mask_wg = 0;         // nf_mask: workgroups per image (0 = the measured default)
+  long nms_mask_k = 1536;       // ... all-pairs bit matrix over the first this-many of them (multiple of 512); later candidates are tested against the kept boxes on the fly
   long nms_fast_k = 2048;       // predict-mode NMS: the three-kernel fast path over the best K candidates per image (<= 2048; 0 = general kernel only)
 };
 extern EyTune g_ey_tune;

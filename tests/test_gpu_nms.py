@@ -149,6 +149,11 @@ def _set_fast_k(k):
     _lib.check(_lib.lib().ey_tune_set(b"nms_fast_k", int(k)), "nms_fast_k")
 
 
+def _lib_tune(name, v):
+    from edge_yolo_amd import _lib
+    _lib.check(_lib.lib().ey_tune_set(name.encode(), int(v)), name)
+
+
 def _fast_meta(ws, B, A):
     """(n_sel, n_total, done) per image from the workspace (layout: nms_fast.inc.h)."""
     P = (A + 255) // 256 * 256
@@ -212,8 +217,11 @@ def test_fast_path_equals_general_kernel_and_oracle(ops, case):
         mask = mask.cuda()
     ref = None
     try:
-        for K in (0, 2048, 1000, 200, 64):
+        # (K, candidates covered by the all-pairs bit matrix): beyond the matrix the resolve kernel tests candidates against the kept boxes
+        # on the fly -- 512 / 1024 put most of the dense cases' work there, 2048 none
+        for K, MK in ((0, 1536), (2048, 1536), (2048, 2048), (2048, 512), (2048, 1024), (1000, 512), (1000, 1536), (200, 1536), (64, 512)):
             _set_fast_k(K)
+            _lib_tune("nms_mask_k", MK)
             boxes, count, index, ws = _ops.nms(x, kw["conf"], kw["iou"], kw["max_det"], 30000, 7680.0, kw["agnostic"], mask, False, return_workspace=True)
             torch.cuda.synchronize()
             got = (boxes.cpu().numpy(), count.cpu().numpy(), index.cpu().numpy())
@@ -226,7 +234,7 @@ def test_fast_path_equals_general_kernel_and_oracle(ops, case):
                     np.testing.assert_array_equal(got[0][b, :n], want[b])
             else:
                 for a, r in zip(got, ref):
-                    np.testing.assert_array_equal(a, r, err_msg=f"{case}: K={K} differs from the general kernel")
+                    np.testing.assert_array_equal(a, r, err_msg=f"{case}: K={K} mask_k={MK} differs from the general kernel")
                 meta = _fast_meta(ws, B, A)
                 for b, (nsel, ntot, done) in enumerate(meta):
                     assert nsel == min(ntot, nsel) and nsel <= K and (nsel == ntot or nsel > 0)
@@ -240,6 +248,7 @@ def test_fast_path_equals_general_kernel_and_oracle(ops, case):
                     assert all(m[2] for m in meta), f"{case}: the fast path should finish every image at K=2048 ({meta})"
     finally:
         _set_fast_k(2048)
+        _lib_tune("nms_mask_k", 1536)
 
 
 def test_fast_path_score_ties_across_the_selection_boundary(ops):
