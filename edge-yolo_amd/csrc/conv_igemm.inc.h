@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvP p) {
 // back as the B fragments of the second conv (lane (r, g) wrote channels 4 NT g ..., reads channels 32 s + 8 g ...: a cross-lane move
 // through the just-written lines, ordered by a workgroup-scope release / acquire pair = one s_waitcnt), second conv, plain epilogue.
 // Same k-step order as the two conv_pw_kernel launches: bit-identical.
-template <int NT>
+template <int NT, bool AG>
 __global__ __launch_bounds__(256) void conv_pwc_kernel(ConvP p, ConvP q) {
   typedef f16 T;
   constexpr int BATCH = NT <= 4 ? 4 : 2;
@@ -1601,8 +1601,9 @@ __global__ __launch_bounds__(256) void conv_pwc_kernel(ConvP p, ConvP q) {
     if (pv) conv_epilogue<T, NT>(p, acc, m, b, oy, ox, ch0, 0);
   }
   // the 16 x Cmid tile this wave just stored is its own input now, laid out across other lanes
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the wave's stores are complete (write-through to L2; the CU's L1 sees its own CU's stores)
+  if constexpr (AG) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // tune pwc = 2: additionally drop the CU's L1 (the by-the-book form for data another CU wrote; not needed here)
+  else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   {  // ---- second conv
     const unsigned voff = pv ? (unsigned)((m * q.srcCs[0] + 8 * g) * 2) : EY_OOB;
     const __amdgpu_buffer_rsrc_t rs = ey_rsrc(q.src[0], q.srcBytes[0]);
@@ -2755,8 +2756,14 @@ extern "C" int ey_conv_pw_pair(const ey_conv_desc* first, const ey_conv_desc* se
     c->ntile = (M + 15) / 16;
   }
   const dim3 grid((unsigned)((p.ntile + 3) / 4));
-  if (nt == 4) hipLaunchKernelGGL((conv_pwc_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
-  else hipLaunchKernelGGL((conv_pwc_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+  const bool ag = tune().pwc == 2;
+  if (nt == 4) {
+    if (ag) hipLaunchKernelGGL((conv_pwc_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL((conv_pwc_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+  } else {
+    if (ag) hipLaunchKernelGGL((conv_pwc_kernel<8, true>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+    else hipLaunchKernelGGL((conv_pwc_kernel<8, false>), grid, dim3(256), 0, (hipStream_t)stream, p, q);
+  }
   EY_LAUNCH_CHECK("ey_conv_pw_pair");
   return EY_OK;
 }

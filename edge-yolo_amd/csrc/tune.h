@@ -32,7 +32,7 @@ struct EyTune {
   long pw_waves = 3072;         // pw: prefer the widest channel tile that still leaves this many waves
   long pw_wmb = 64;             // pw: ... while (#16-pixel tiles x weight bytes), the L2->CU weight traffic, stays below this many MiB
   long xcd_map = 31;            // XCD-contiguous work order (ey_xcd_block): bit 0 = depthwise 3x3 strips, 1 = Toeplitz DSConv tiles, 2 = wavelet_z tiles, 3 = 3x3 stream conv, 4 = 3x3 tile conv
-  long pwc = 1;                 // enhancer tail conv + the 1x1 behind it as one launch (conv_pwc_kernel; 0 = two launches)
+  long pwc = 1;                 // enhancer tail conv + the 1x1 behind it as one launch (conv_pwc_kernel; 0 = two launches, 2 = with an agent-scope acquire)
   long pwn = 1;                 // N-split pointwise kernel (small maps, K 128..512, Cout % 128 == 0; 0 = off)
   long pwn_max_m = 110000;      // ... up to this many output pixels
   long pwn_ntw = 0;             // ... developer knob: 16-channel blocks per wave (1, 2; 0 = rule)
