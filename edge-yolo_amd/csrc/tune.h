@@ -41,7 +41,7 @@ struct EyTune {
   long tz_minpx = 100000;       // ... k = 3/5 only on maps with at least this many pixels (k = 7 always)
   long ds_strip = 1;            // dsconv register-strip kernel (0 = off)
   long dsb_pair = 1;            // DSBottleneck pair (k3 -> k5/k7 DSConv + residual) as one band kernel on small maps (0 = two launches)
-  long dsb_max_px = 100000;     // ... for maps up to this many pixels (B x H x W)
+  long dsb_max_px = 300000;     // ... for maps up to this many pixels (B x H x W) -- 300 k also takes the C32 k7 pairs at 80x80, batch 32: isolated the band kernel is 10 % slower there than the two Toeplitz launches (44 vs 40 us), in the batch pipeline the step is 1.3 % faster (one launch, no 13 MB round trip; single graph +0.7 %)
   long dsb_rb = 0;              // ... developer knob: rows per band (0 = cost rule)
   long dsb_p2 = 0;              // ... developer knob: strip length of the second stage (1, 2, 4; 0 = rule)
   long dsb_fixed = 100;         // ... cost rule: fixed cost of a workgroup in stencil row-taps

@@ -42,7 +42,7 @@ def _module(c, k2, add=True, seed=0):
 
 
 # (channels, k2, batch, H, W): the eight pairs of the EdgeLine-n step at batch 32 (layers 4, 6, 13, 16, 19, 22), then ragged maps
-SHAPES = [(32, 5, 32, 40, 40), (64, 5, 32, 20, 20), (64, 7, 32, 40, 40), (32, 7, 3, 13, 9), (64, 5, 2, 7, 5), (64, 7, 5, 22, 25), (32, 5, 1, 3, 33), (64, 5, 4, 1, 1)]
+SHAPES = [(32, 5, 32, 40, 40), (64, 5, 32, 20, 20), (64, 7, 32, 40, 40), (32, 7, 32, 80, 80), (32, 7, 3, 13, 9), (64, 5, 2, 7, 5), (64, 7, 5, 22, 25), (32, 5, 1, 3, 33), (64, 5, 4, 1, 1)]
 
 
 @pytest.mark.parametrize("c,k2,b,h,w", SHAPES)
@@ -93,7 +93,7 @@ def test_views_and_no_shortcut():
 
 def test_shapes_outside_the_kernel_run_as_two_launches():
     from edge_yolo_amd.nn import modules as M
-    for c, k1, k2, hw in [(16, 3, 7, 20), (64, 3, 3, 20), (128, 3, 5, 10), (32, 3, 5, 200)]:
+    for c, k1, k2, hw in [(16, 3, 7, 20), (64, 3, 3, 20), (128, 3, 5, 10), (32, 3, 5, 200), (32, 3, 7, 400)]:
         m = M.DSBottleneck(c, c, shortcut=True, e=1.0, k1=k1, k2=k2)
         load_synth(m, "dsbo")
         m = to_dev(m, torch.float16)
